@@ -1,0 +1,207 @@
+// Scalar arithmetic mod l = 2^252 + 27742317777372353535851937790883648493 for gfx950.
+//
+// 8 saturated 32-bit limbs, canonical (< l) between operations; products go through two 8x8 CIOS
+// Montgomery passes (R = 2^256) so every stored scalar is in plain form and byte-compatible with the
+// 32-byte little-endian encoding the reference uses on the wire and in the transcript.
+//
+// Replaces the role of curve25519-dalek 1.2.3 `Scalar` (un-vendored):
+// from_bytes_mod_order_wide (src/blindbid/mod.rs:16), from_bits (src/blindbid/bid.rs:27,
+// src/blindbid/verify.rs:115), invert, + - * as used throughout bulletproofs' r1cs prover/verifier.
+#pragma once
+#include "field.h"
+
+namespace bbp {
+
+struct sc {
+    u32 v[8];
+};
+
+#define BBP_SC_LIT(a0, a1, a2, a3, a4, a5, a6, a7) \
+    sc { { a0, a1, a2, a3, a4, a5, a6, a7 } }
+
+BBP_HD sc sc_zero() { return BBP_SC_LIT(0, 0, 0, 0, 0, 0, 0, 0); }
+BBP_HD sc sc_one() { return BBP_SC_LIT(1, 0, 0, 0, 0, 0, 0, 0); }
+BBP_HD sc sc_l() { return BBP_SC_LIT(0x5cf5d3edu, 0x5812631au, 0xa2f79cd6u, 0x14def9deu, 0, 0, 0, 0x10000000u); }
+BBP_HD sc sc_rr() { return BBP_SC_LIT(0x449c0f01u, 0xa40611e3u, 0x68859347u, 0xd00e1ba7u, 0x17f5be65u, 0xceec73d2u, 0x7c309a3du, 0x0399411bu); }
+BBP_HD sc sc_r() { return BBP_SC_LIT(0x8d98951du, 0xd6ec3174u, 0x737dcf70u, 0xc6ef5bf4u, 0xfffffffeu, 0xffffffffu, 0xffffffffu, 0x0fffffffu); }
+#define BBP_SC_LFACTOR 0x12547e1bu
+
+BBP_HD sc sc_from_u32(u32 x) { return BBP_SC_LIT(x, 0, 0, 0, 0, 0, 0, 0); }
+BBP_HD sc sc_from_u64(u64 x) { return BBP_SC_LIT((u32)x, (u32)(x >> 32), 0, 0, 0, 0, 0, 0); }
+
+// r = a - l if a >= l (a < 2l, optional 9th limb `hi`)
+BBP_HD sc sc_cond_sub_l(const sc& a, u32 hi) {
+    sc l = sc_l(), t;
+    int64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c += (int64_t)a.v[i] - (int64_t)l.v[i];
+        t.v[i] = (u32)c;
+        c >>= 32;
+    }
+    c += hi;  // borrow (-1) cancels against hi == 1
+    u32 keep_a = (u32)(c < 0);
+    u32 m = 0u - keep_a;
+    sc r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = (a.v[i] & m) | (t.v[i] & ~m);
+    return r;
+}
+
+BBP_HD sc sc_add(const sc& a, const sc& b) {
+    sc r;
+    u64 c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c += (u64)a.v[i] + b.v[i];
+        r.v[i] = (u32)c;
+        c >>= 32;
+    }
+    return sc_cond_sub_l(r, (u32)c);
+}
+
+BBP_HD sc sc_sub(const sc& a, const sc& b) {
+    sc r, l = sc_l();
+    int64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c += (int64_t)a.v[i] - (int64_t)b.v[i];
+        r.v[i] = (u32)c;
+        c >>= 32;
+    }
+    u32 m = (u32)c;  // 0 or 0xffffffff
+    u64 k = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        k += (u64)r.v[i] + (l.v[i] & m);
+        r.v[i] = (u32)k;
+        k >>= 32;
+    }
+    return r;
+}
+
+BBP_HD sc sc_neg(const sc& a) { return sc_sub(sc_zero(), a); }
+
+// Montgomery product a*b*2^-256 mod l; needs a*b < 2^256 * l; result canonical
+BBP_HD sc sc_montmul(const sc& a, const sc& b) {
+    const sc l = sc_l();
+    u32 t[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u64 c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            c += (u64)a.v[j] * b.v[i] + t[j];
+            t[j] = (u32)c;
+            c >>= 32;
+        }
+        c += t[8];
+        t[8] = (u32)c;
+        t[9] = (u32)(c >> 32);
+        u32 m = t[0] * BBP_SC_LFACTOR;
+        c = (u64)m * l.v[0] + t[0];
+        c >>= 32;
+#pragma unroll
+        for (int j = 1; j < 8; j++) {
+            c += (u64)m * l.v[j] + t[j];
+            t[j - 1] = (u32)c;
+            c >>= 32;
+        }
+        c += t[8];
+        t[7] = (u32)c;
+        c >>= 32;
+        t[8] = t[9] + (u32)c;
+    }
+    sc r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = t[i];
+    return sc_cond_sub_l(r, t[8]);
+}
+
+BBP_HD sc sc_to_mont(const sc& a) { return sc_montmul(a, sc_rr()); }
+BBP_HD sc sc_from_mont(const sc& a) { return sc_montmul(a, sc_one()); }
+BBP_HD sc sc_mul(const sc& a, const sc& b) { return sc_montmul(sc_montmul(a, b), sc_rr()); }
+BBP_HD sc sc_sq(const sc& a) { return sc_mul(a, a); }
+// a*b + c
+BBP_HD sc sc_muladd(const sc& a, const sc& b, const sc& c) { return sc_add(sc_mul(a, b), c); }
+
+// any 256-bit value (8 LE words) -> canonical scalar (a < 2^256 < 16 l is allowed into montmul)
+BBP_HD sc sc_reduce256(const u32* w) {
+    sc a;
+#pragma unroll
+    for (int i = 0; i < 8; i++) a.v[i] = w[i];
+    return sc_montmul(sc_montmul(a, sc_rr()), sc_one());
+}
+
+// Scalar::from_bytes_mod_order_wide: 16 LE words
+BBP_HD sc sc_from_wide(const u32* w) {
+    sc lo, hi;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        lo.v[i] = w[i];
+        hi.v[i] = w[i + 8];
+    }
+    sc lo_mod = sc_montmul(sc_montmul(lo, sc_rr()), sc_one());  // lo mod l
+    sc hi_r = sc_montmul(hi, sc_rr());                         // hi * 2^256 mod l
+    return sc_add(lo_mod, hi_r);
+}
+
+// Scalar::from_bits semantics as the reference uses them (bit 255 cleared, then used mod l)
+BBP_HD sc sc_from_bits(const u32* w) {
+    u32 t[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) t[i] = w[i];
+    t[7] &= 0x7fffffffu;
+    return sc_reduce256(t);
+}
+
+BBP_HD bool sc_is_canonical(const u32* w) {
+    sc l = sc_l();
+    int64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c += (int64_t)w[i] - (int64_t)l.v[i];
+        c >>= 32;
+    }
+    return c < 0;
+}
+
+BBP_HD bool sc_iszero(const sc& a) {
+    u32 o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o |= a.v[i];
+    return o == 0;
+}
+
+BBP_HD bool sc_eq(const sc& a, const sc& b) {
+    u32 o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o |= a.v[i] ^ b.v[i];
+    return o == 0;
+}
+
+// a^(l-2): square-and-multiply over the constant exponent, in Montgomery form
+BBP_HD_NOINLINE sc sc_invert(const sc& a) {
+    const u32 e[8] = {0x5cf5d3ebu, 0x5812631au, 0xa2f79cd6u, 0x14def9deu, 0, 0, 0, 0x10000000u};
+    sc am = sc_to_mont(a);
+    sc acc = sc_r();  // 1 in Montgomery form
+    for (int i = 255; i >= 0; i--) {
+        acc = sc_montmul(acc, acc);
+        if ((e[i >> 5] >> (i & 31)) & 1u) acc = sc_montmul(acc, am);
+    }
+    return sc_from_mont(acc);
+}
+
+BBP_HD void sc_tobytes(uint8_t* out, const sc& a) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        out[4 * i + 0] = (uint8_t)(a.v[i]);
+        out[4 * i + 1] = (uint8_t)(a.v[i] >> 8);
+        out[4 * i + 2] = (uint8_t)(a.v[i] >> 16);
+        out[4 * i + 3] = (uint8_t)(a.v[i] >> 24);
+    }
+}
+
+}  // namespace bbp

@@ -1,0 +1,136 @@
+// Test-only shim: compiles the PRODUCT's limb arithmetic headers for the host CPU so the not-gpu test
+// tier can compare them with the oracle.  Nothing in the shipped library calls this.
+#include <string.h>
+
+#include "../dusk_blindbidproof_amd/csrc/keccak.h"
+#include "../dusk_blindbidproof_amd/csrc/point.h"
+#include "../dusk_blindbidproof_amd/csrc/scalar.h"
+
+using namespace bbp;
+
+static void ld(u32* w, const uint8_t* b, int nwords) { memcpy(w, b, 4 * nwords); }
+
+extern "C" {
+
+// op: 0 add, 1 sub, 2 mul, 3 sq, 4 invert, 5 canon(a), 6 neg, 7 pow22523, 8 mul_small(a, b[0])
+void hc_fe_op(int op, const uint8_t* a32, const uint8_t* b32, uint8_t* out32) {
+    fe a, b, r;
+    ld(a.v, a32, 8);
+    ld(b.v, b32, 8);
+    switch (op) {
+        case 0: r = fe_add(a, b); break;
+        case 1: r = fe_sub(a, b); break;
+        case 2: r = fe_mul(a, b); break;
+        case 3: r = fe_sq(a); break;
+        case 4: r = fe_invert(a); break;
+        case 5: r = a; break;
+        case 6: r = fe_neg(a); break;
+        case 7: r = fe_pow22523(a); break;
+        default: r = fe_mul_small(a, b.v[0] & 0x3ffffffu); break;
+    }
+    fe_tobytes(out32, r);
+}
+
+// op: 0 add, 1 sub, 2 mul, 3 invert, 4 from_wide(a64), 5 from_bits(a32), 6 neg
+void hc_sc_op(int op, const uint8_t* a, const uint8_t* b32, uint8_t* out32) {
+    sc x, y, r;
+    u32 w[16];
+    if (op == 4) {
+        ld(w, a, 16);
+        r = sc_from_wide(w);
+    } else if (op == 5) {
+        ld(w, a, 8);
+        r = sc_from_bits(w);
+    } else {
+        ld(x.v, a, 8);
+        ld(y.v, b32, 8);
+        switch (op) {
+            case 0: r = sc_add(x, y); break;
+            case 1: r = sc_sub(x, y); break;
+            case 2: r = sc_mul(x, y); break;
+            case 3: r = sc_invert(x); break;
+            default: r = sc_neg(x); break;
+        }
+    }
+    sc_tobytes(out32, r);
+}
+
+int hc_sc_is_canonical(const uint8_t* a32) {
+    u32 w[8];
+    ld(w, a32, 8);
+    return sc_is_canonical(w) ? 1 : 0;
+}
+
+// decode -> (op) -> encode.  op: 0 identity map (round trip), 1 double, 2 add(a,b), 3 sub(a,b),
+// 4 madd(a, niels(b)), 5 msub(a, niels(b)).  Returns 0 if a decode failed.
+int hc_ge_op(int op, const uint8_t* a32, const uint8_t* b32, uint8_t* out32) {
+    u32 w[8];
+    ge a, b, r;
+    ld(w, a32, 8);
+    if (!ge_decode_words(a, w)) return 0;
+    ld(w, b32, 8);
+    if (op >= 2 && !ge_decode_words(b, w)) return 0;
+    switch (op) {
+        case 0: r = a; break;
+        case 1: r = ge_dbl(a); break;
+        case 2: r = ge_add(a, b); break;
+        case 3: r = ge_sub(a, b); break;
+        case 4: r = ge_madd(a, ge_to_niels(b, fe_invert(b.Z))); break;
+        default: r = ge_msub(a, ge_to_niels(b, fe_invert(b.Z))); break;
+    }
+    ge_encode(out32, r);
+    return 1;
+}
+
+void hc_from_uniform(const uint8_t* in64, uint8_t* out32) {
+    u32 w[16];
+    ld(w, in64, 16);
+    ge_encode(out32, ge_from_uniform_words(w));
+}
+
+void hc_basepoint(uint8_t* out32) { ge_encode(out32, ge_basepoint()); }
+
+// scalar * point by double-and-add (test helper)
+int hc_scalarmult(const uint8_t* s32, const uint8_t* p32, uint8_t* out32) {
+    u32 w[8], s[8];
+    ge p;
+    ld(w, p32, 8);
+    if (!ge_decode_words(p, w)) return 0;
+    ld(s, s32, 8);
+    ge acc = ge_identity();
+    for (int i = 255; i >= 0; i--) {
+        acc = ge_dbl(acc);
+        if ((s[i >> 5] >> (i & 31)) & 1u) acc = ge_add(acc, p);
+    }
+    ge_encode(out32, acc);
+    return 1;
+}
+
+void hc_keccak_f(uint8_t* st200) {
+    u64 s[25];
+    memcpy(s, st200, 200);
+    keccak_f1600(s);
+    memcpy(st200, s, 200);
+}
+
+// merlin: Transcript(label) ; append_message(l1, m1) ; challenge_bytes(l2, n)
+void hc_merlin_kat(const uint8_t* label, int label_len, const uint8_t* l1, int l1_len, const uint8_t* m1, int m1_len,
+                   const uint8_t* l2, int l2_len, uint8_t* out, int n) {
+    merlin_transcript t;
+    merlin_init(t, label, label_len);
+    merlin_append(t, l1, l1_len, m1, m1_len);
+    merlin_challenge(t, l2, l2_len, out, n);
+}
+
+// TranscriptRng: Transcript(label); rng = build_rng().rekey(wl, w).finalize(ent32); fill n bytes twice
+void hc_merlin_rng(const uint8_t* label, int label_len, const uint8_t* wl, int wl_len, const uint8_t* w, int w_len,
+                   const uint8_t* ent32, uint8_t* out, int n) {
+    merlin_transcript t;
+    merlin_init(t, label, label_len);
+    merlin_transcript r = t;
+    merlin_rng_rekey(r, wl, wl_len, w, w_len);
+    merlin_rng_finalize(r, ent32);
+    merlin_rng_fill(r, out, n);
+    merlin_rng_fill(r, out + n, n);
+}
+}
