@@ -1,0 +1,155 @@
+"""ctypes binding of include/bbp.h. Fails loudly when the HIP library is missing: there is no fallback."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+lib_path = os.path.join(_HERE, "libbbp_hip.so")
+
+STATUS = {0: "OK", 1: "VERIFY", 2: "GENS_LEN", 3: "FORMAT", 4: "BAD_ARG", 5: "DEVICE"}
+LAYOUT_BLIND_G_H, LAYOUT_BLIND_G = 0, 1
+BASE_BBLIND, BASE_G0, BASE_H0, BASE_B, NUM_BASES = 0, 1, 2049, 4097, 4098
+R1CS_PROOF_BYTES = 1121
+
+# every symbol include/bbp.h declares: (restype, argtypes)
+_vp, _u32, _i32, _u64, _cp = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int32, ctypes.c_uint64, ctypes.c_char_p
+SIGNATURES = {
+    "bbp_init": (_i32, [_i32, ctypes.POINTER(_vp)]),
+    "bbp_free": (None, [_vp]),
+    "bbp_last_error": (_cp, [_vp]),
+    "bbp_get_generator": (_i32, [_vp, _u32, _vp]),
+    "bbp_get_mimc_constant": (_i32, [_vp, _u32, _vp]),
+    "bbp_msm_batch": (_i32, [_vp, _u32, _u32, _vp, _u32, _vp]),
+    "bbp_msm_batch_dev": (_i32, [_vp, _u32, _u32, _vp, _u32, _vp, _vp]),
+    "bbp_witness_batch": (_i32, [_vp, _u32, _vp, _vp]),
+    "bbp_prove": (_i32, [_vp, _vp, _vp, _u32, _u64, _vp, _vp, ctypes.POINTER(_u32)]),
+    "bbp_proof_record_size": (_u32, [_u32]),
+    "bbp_entropy_size": (_u32, [_u32]),
+    "bbp_verify": (_i32, [_vp, _vp, _u32, _vp, _vp, _vp, _vp, _u32]),
+    "bbp_prove_batch": (_i32, [_vp, _u32, _u32, _vp, _vp, _vp, _vp]),
+    "bbp_verify_batch": (_i32, [_vp, _u32, _u32, _vp, _vp]),
+    "bbp_last_timings": (_i32, [_vp, _vp, _u32, ctypes.POINTER(_u32)]),
+}
+
+
+class BbpError(RuntimeError):
+    def __init__(self, status, msg=""):
+        super().__init__("bbp status %d (%s) %s" % (status, STATUS.get(status, "?"), msg))
+        self.status = status
+
+
+def _load():
+    if not os.path.exists(lib_path):
+        raise ImportError("libbbp_hip.so not built (run `python __graft_entry__.py`); there is no CPU fallback")
+    L = ctypes.CDLL(lib_path)
+    for name, (res, args) in SIGNATURES.items():
+        f = getattr(L, name)  # AttributeError here = the .so does not export what include/bbp.h declares
+        f.restype, f.argtypes = res, args
+    return L
+
+
+lib = _load()
+
+
+def record_size(n):
+    return R1CS_PROOF_BYTES + 32 * (4 + n)
+
+
+def entropy_size(n):
+    return 32 * (4 + n) + 32
+
+
+def _buf(b):
+    return (ctypes.c_uint8 * len(b)).from_buffer_copy(bytes(b))
+
+
+class Context:
+    """One engine context per GPU (bbp_init). Mirrors the reference's implicit process-wide state
+    (lazy_static CONSTANTS + generate_cs_transcript, src/blindbid/mod.rs:7-40) as an explicit handle."""
+
+    def __init__(self, device=0):
+        self._h = ctypes.c_void_p()
+        rc = lib.bbp_init(device, ctypes.byref(self._h))
+        if rc != 0:
+            msg = lib.bbp_last_error(self._h).decode() if self._h else "no usable HIP device"
+            if self._h:
+                lib.bbp_free(self._h)
+                self._h = None
+            raise BbpError(rc, msg)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.bbp_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise BbpError(rc, lib.bbp_last_error(self._h).decode())
+
+    @property
+    def handle(self):
+        return self._h
+
+    def generator(self, index):
+        out = (ctypes.c_uint8 * 32)()
+        self._check(lib.bbp_get_generator(self._h, index, out))
+        return bytes(out)
+
+    def mimc_constant(self, i):
+        out = (ctypes.c_uint8 * 32)()
+        self._check(lib.bbp_get_mimc_constant(self._h, i, out))
+        return bytes(out)
+
+    def msm_batch(self, B, n_terms, scalars, layout):
+        assert len(scalars) == B * n_terms * 32
+        out = (ctypes.c_uint8 * (32 * B))()
+        self._check(lib.bbp_msm_batch(self._h, B, n_terms, _buf(scalars), layout, out))
+        return bytes(out)
+
+    def msm_batch_dev(self, B, n_terms, scalars_ptr, layout, out_ptr, stream=0):
+        self._check(lib.bbp_msm_batch_dev(self._h, B, n_terms, scalars_ptr, layout, out_ptr, stream))
+
+    def witness_batch(self, dks):
+        B = len(dks) // 96
+        out = (ctypes.c_uint8 * (192 * B))()
+        self._check(lib.bbp_witness_batch(self._h, B, _buf(dks), out))
+        return bytes(out)
+
+    def prove(self, scalars7, pub_list, toggle, entropy=None):
+        """Proof::prove (src/blindbid/proof.rs:36-46) -> raw record (R1CSProof || commitments || t_c)."""
+        n = len(pub_list) // 32
+        out = (ctypes.c_uint8 * record_size(max(n, 1)))()
+        plen = ctypes.c_uint32()
+        ent = _buf(entropy) if entropy is not None else None
+        self._check(lib.bbp_prove(self._h, _buf(scalars7), _buf(pub_list) if n else None, n, toggle, ent, out,
+                                  ctypes.byref(plen)))
+        return bytes(out)[:record_size(n)]
+
+    def verify(self, record, score, z_img, seed, pub_list):
+        """Verify::verify (src/blindbid/verify.rs:47): returns the bbp_status (0 = Ok(()))."""
+        n = len(pub_list) // 32
+        return lib.bbp_verify(self._h, _buf(record), len(record), _buf(score), _buf(z_img), _buf(seed),
+                              _buf(pub_list) if n else None, n)
+
+    def prove_batch(self, B, N, inputs, entropy=None):
+        out = (ctypes.c_uint8 * (B * record_size(N)))()
+        status = (ctypes.c_int32 * B)()
+        ent = _buf(entropy) if entropy is not None else None
+        self._check(lib.bbp_prove_batch(self._h, B, N, _buf(inputs), ent, out, status))
+        return bytes(out), list(status)
+
+    def verify_batch(self, B, N, inputs):
+        status = (ctypes.c_int32 * B)()
+        self._check(lib.bbp_verify_batch(self._h, B, N, _buf(inputs), status))
+        return list(status)
+
+    def last_timings(self):
+        arr = (ctypes.c_float * 64)()
+        n = ctypes.c_uint32()
+        lib.bbp_last_timings(self._h, arr, 64, ctypes.byref(n))
+        return list(arr)[:n.value]

@@ -1,0 +1,83 @@
+// C-ABI: kernel-level MSM hook (BASELINE.json configs[1]) -- see include/bbp.h.
+#include <string.h>
+
+#include "context.h"
+
+using namespace bbp;
+
+namespace bbp {
+
+// base indices (generator-table order) of a layout's terms
+int32_t layout_base_indices(uint32_t layout, uint32_t n_terms, std::vector<u32>& idx, std::string& err) {
+    idx.clear();
+    if (layout == BBP_LAYOUT_BLIND_G_H) {
+        if (n_terms < 1 || (n_terms - 1) % 2 != 0 || (n_terms - 1) / 2 > BBP_GENS_CAPACITY) {
+            err = "layout 0 needs n_terms = 1 + 2m, m <= 2048";
+            return BBP_ERR_BAD_ARG;
+        }
+        u32 m = (n_terms - 1) / 2;
+        idx.push_back(BBP_BASE_BBLIND);
+        for (u32 i = 0; i < m; i++) idx.push_back(BBP_BASE_G0 + i);
+        for (u32 i = 0; i < m; i++) idx.push_back(BBP_BASE_H0 + i);
+        return BBP_OK;
+    }
+    if (layout == BBP_LAYOUT_BLIND_G) {
+        if (n_terms < 1 || n_terms - 1 > BBP_GENS_CAPACITY) {
+            err = "layout 1 needs n_terms = 1 + m, m <= 2048";
+            return BBP_ERR_BAD_ARG;
+        }
+        idx.push_back(BBP_BASE_BBLIND);
+        for (u32 i = 0; i + 1 < n_terms; i++) idx.push_back(BBP_BASE_G0 + i);
+        return BBP_OK;
+    }
+    err = "unknown layout";
+    return BBP_ERR_BAD_ARG;
+}
+
+}  // namespace bbp
+
+extern "C" int32_t bbp_msm_batch_dev(bbp_ctx* ctx, uint32_t B, uint32_t n_terms, const void* scalars_dev, uint32_t layout,
+                                     void* out32_dev, void* stream_) {
+    if (!ctx || !scalars_dev || !out32_dev) return BBP_ERR_BAD_ARG;
+    if (B == 0) return BBP_OK;
+    BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t stream = stream_ ? (hipStream_t)stream_ : ctx->stream;
+    std::vector<u32> idx;
+    int32_t rc = layout_base_indices(layout, n_terms, idx, ctx->err);
+    if (rc) return rc;
+    rc = dev_reserve(ctx, ctx->idx, idx.size() * 4);
+    if (rc) return rc;
+    rc = dev_reserve(ctx, ctx->pts, sizeof(ge) * (size_t)B);
+    if (rc) return rc;
+    BBP_HIP_TRY(ctx, hipMemcpyAsync(ctx->idx.p, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, stream));
+    rc = msm_launch(ctx, B, n_terms, (const u32*)scalars_dev, (const u32*)ctx->idx.p, (ge*)ctx->pts.p, stream);
+    if (rc) return rc;
+    return encode_launch(ctx, B, (const ge*)ctx->pts.p, (uint8_t*)out32_dev, stream);
+}
+
+extern "C" int32_t bbp_msm_batch(bbp_ctx* ctx, uint32_t B, uint32_t n_terms, const uint8_t* scalars, uint32_t layout,
+                                 uint8_t* out32) {
+    if (!ctx || !scalars || !out32) return BBP_ERR_BAD_ARG;
+    if (B == 0) return BBP_OK;
+    BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // canonical scalars only (the reference's Scalars are always reduced)
+    const size_t total = (size_t)B * n_terms;
+    for (size_t i = 0; i < total; i++) {
+        u32 w[8];
+        memcpy(w, scalars + 32 * i, 32);
+        if (!sc_is_canonical(w)) {
+            ctx->err = "bbp_msm_batch: non-canonical scalar";
+            return BBP_ERR_FORMAT;
+        }
+    }
+    int32_t rc = dev_reserve(ctx, ctx->scal, total * 32);
+    if (rc) return rc;
+    rc = dev_reserve(ctx, ctx->enc, (size_t)B * 32);
+    if (rc) return rc;
+    BBP_HIP_TRY(ctx, hipMemcpyAsync(ctx->scal.p, scalars, total * 32, hipMemcpyHostToDevice, ctx->stream));
+    rc = bbp_msm_batch_dev(ctx, B, n_terms, ctx->scal.p, layout, ctx->enc.p, ctx->stream);
+    if (rc) return rc;
+    BBP_HIP_TRY(ctx, hipMemcpyAsync(out32, ctx->enc.p, (size_t)B * 32, hipMemcpyDeviceToHost, ctx->stream));
+    BBP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return BBP_OK;
+}

@@ -1,0 +1,74 @@
+// Engine context shared by the translation units of libbbp_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/bbp.h"
+#include "point.h"
+#include "scalar.h"
+
+namespace bbp {
+
+// ---- MSM geometry (see DESIGN.md "K1") ---------------------------------------------------------------
+constexpr int MSM_C = 11;                 // window bits (signed digits in [-1023, 1024])
+constexpr int MSM_W = 24;                 // windows: 24 * 11 = 264 >= 256 bits
+constexpr int MSM_K = 1 << (MSM_C - 1);   // 1024 buckets (|digit| = 1..1024)
+constexpr int MSM_T = 128;                // threads per MSM workgroup (2 wavefronts)
+constexpr int MSM_G = MSM_K / MSM_T;      // 8 consecutive buckets per lane
+constexpr int MSM_LOG_G = 3;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+}  // namespace bbp
+
+struct bbp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // resident tables
+    bbp::ge* gens = nullptr;           // [BBP_NUM_BASES] extended points: B_blinding, G[2048], H[2048], B
+    bbp::ge_niels* wtable = nullptr;   // [BBP_NUM_BASES * MSM_W] affine cached 2^(11 j) * P_i
+    bbp::ge_niels* comb = nullptr;     // [2][64][8] radix-16 comb for B and B_blinding (small commits)
+    bbp::sc* mimc_c = nullptr;         // [90]
+    uint8_t gens_enc_host_valid = 0;
+    std::vector<uint8_t> mimc_host;    // 90 * 32
+    // grow-only scratch
+    bbp::DevBuf scal, idx, sorted, pts, enc, misc;
+    std::vector<float> timings;
+};
+
+namespace bbp {
+
+#define BBP_HIP_TRY(ctx, expr)                                                                         \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) {                                                                        \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                            \
+            return BBP_ERR_DEVICE;                                                                     \
+        }                                                                                              \
+    } while (0)
+
+inline int32_t dev_reserve(bbp_ctx* ctx, DevBuf& b, size_t bytes) {
+    if (b.cap >= bytes) return BBP_OK;
+    if (b.p) BBP_HIP_TRY(ctx, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    size_t want = bytes + (bytes >> 3) + 4096;
+    BBP_HIP_TRY(ctx, hipMalloc(&b.p, want));
+    b.cap = want;
+    return BBP_OK;
+}
+
+// msm.hip
+int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* scalars_dev, const u32* base_idx_dev,
+                   ge* out_points_dev, hipStream_t stream);
+int32_t encode_launch(bbp_ctx* ctx, uint32_t n, const ge* pts_dev, uint8_t* out32_dev, hipStream_t stream);
+size_t msm_scratch_bytes(uint32_t n_msm, uint32_t n_terms);
+
+}  // namespace bbp

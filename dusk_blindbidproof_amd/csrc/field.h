@@ -13,7 +13,7 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define BBP_HD __host__ __device__ __forceinline__
-#define BBP_HD_NOINLINE __host__ __device__ __noinline__
+#define BBP_HD_NOINLINE __host__ __device__ inline __attribute__((noinline))
 #else
 #define BBP_HD inline
 #define BBP_HD_NOINLINE inline

@@ -1,0 +1,221 @@
+// K1: batched fixed-base multiscalar multiplication over the resident generator table (Pippenger bucketing).
+//
+// Replaces the point work bulletproofs does through RistrettoPoint::{multiscalar_mul, vartime_multiscalar_mul}
+// (dalek constant-time Straus / vartime Straus-or-Pippenger) under Prover::prove and
+// Verifier::verify, reached from src/blindbid/proof.rs:88 and src/blindbid/verify.rs:88.  Any evaluation order
+// gives the same group element, and the ristretto encoding is canonical, so outputs are byte-identical.
+//
+// One workgroup (2 wavefronts, 128 lanes) owns one MSM:
+//   A. signed 11-bit digits of every scalar -> LDS histogram over |digit| (1024 buckets)
+//   B. exclusive scan -> bucket offsets (each lane owns 8 consecutive buckets)
+//   C. counting-sort scatter of (table index, sign) into the workgroup's HBM scratch slice
+//   D. each lane walks its 8 buckets high->low: bucket sum by mixed additions of cached affine table entries
+//      2^(11 j) * P_i (no doublings anywhere: the window shift is precomputed in the table), then the classic
+//      running-sum fold (running += bucket; total += running)
+//   E. cross-lane fold through LDS: suffix scan of the lane sums, weight by 8, tree reduce.
+#include "context.h"
+
+namespace bbp {
+
+__device__ __forceinline__ void lds_put(u32* stage, int t, const ge& p) {
+    const u32* w = reinterpret_cast<const u32*>(&p);
+#pragma unroll
+    for (int i = 0; i < 32; i++) stage[i * MSM_T + t] = w[i];
+}
+
+__device__ __forceinline__ ge lds_get(const u32* stage, int t) {
+    ge p;
+    u32* w = reinterpret_cast<u32*>(&p);
+#pragma unroll
+    for (int i = 0; i < 32; i++) w[i] = stage[i * MSM_T + t];
+    return p;
+}
+
+__device__ __forceinline__ ge_niels load_niels(const ge_niels* __restrict__ tab, u32 entry) {
+    const uint4* p = reinterpret_cast<const uint4*>(tab + (entry & 0x7fffffffu));
+    uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4], q5 = p[5];
+    ge_niels n;
+    n.ypx = BBP_FE_LIT(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w);
+    n.ymx = BBP_FE_LIT(q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w);
+    n.xy2d = BBP_FE_LIT(q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w);
+    // negative digit: -(x, y) = (-x, y) swaps y+x / y-x and negates 2dxy
+    bool neg = entry >> 31;
+    fe a = fe_select(n.ypx, n.ymx, neg);
+    fe b = fe_select(n.ymx, n.ypx, neg);
+    n.xy2d = fe_select(n.xy2d, fe_neg(n.xy2d), neg);
+    n.ypx = a;
+    n.ymx = b;
+    return n;
+}
+
+// signed-digit walk over one scalar; calls f(j, magnitude, negative) for every non-zero digit
+template <class F>
+__device__ __forceinline__ void for_each_digit(const u32 (&s)[8], F&& f) {
+    u32 carry = 0;
+#pragma unroll
+    for (int j = 0; j < MSM_W; j++) {
+        const int o = j * MSM_C, w = o >> 5, sh = o & 31;
+        u32 raw = 0;
+        if (w < 8) {
+            raw = s[w] >> sh;
+            if (sh + MSM_C > 32 && w + 1 < 8) raw |= s[w + 1] << (32 - sh);
+        }
+        raw &= (1u << MSM_C) - 1u;
+        u32 d = raw + carry;
+        carry = d > (u32)MSM_K;
+        u32 mag = carry ? (2u * MSM_K - d) : d;
+        if (mag) f(j, mag, carry);
+    }
+}
+
+__global__ __launch_bounds__(MSM_T) void k_msm(const u32* __restrict__ scalars, const u32* __restrict__ base_idx, u32 n,
+                                                const ge_niels* __restrict__ wtable, u32* __restrict__ sorted_all,
+                                                ge* __restrict__ out) {
+    __shared__ u32 cnt[MSM_K + 1];
+    __shared__ u32 cursor[MSM_K + 1];
+    __shared__ u32 part[MSM_T];
+    __shared__ u32 stage[32 * MSM_T];
+    const int tid = threadIdx.x;
+    const size_t msm = blockIdx.x;
+    const u32* sbase = scalars + msm * (size_t)n * 8;
+    u32* sorted = sorted_all + msm * (size_t)n * MSM_W;
+
+    for (int k = tid; k <= MSM_K; k += MSM_T) cnt[k] = 0;
+    __syncthreads();
+
+    // A. histogram
+    for (u32 i = tid; i < n; i += MSM_T) {
+        const uint4* sp = reinterpret_cast<const uint4*>(sbase + (size_t)i * 8);
+        uint4 lo = sp[0], hi = sp[1];
+        const u32 s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        for_each_digit(s, [&](int, u32 mag, u32) { atomicAdd(&cnt[mag], 1u); });
+    }
+    __syncthreads();
+
+    // B. offsets
+    {
+        u32 local = 0;
+#pragma unroll
+        for (int r = 1; r <= MSM_G; r++) local += cnt[tid * MSM_G + r];
+        part[tid] = local;
+        __syncthreads();
+        if (tid == 0) {
+            u32 run = 0;
+            for (int t = 0; t < MSM_T; t++) {
+                u32 v = part[t];
+                part[t] = run;
+                run += v;
+            }
+        }
+        __syncthreads();
+        u32 base = part[tid];
+#pragma unroll
+        for (int r = 1; r <= MSM_G; r++) {
+            cursor[tid * MSM_G + r] = base;
+            base += cnt[tid * MSM_G + r];
+        }
+    }
+    __syncthreads();
+
+    // C. scatter
+    for (u32 i = tid; i < n; i += MSM_T) {
+        const uint4* sp = reinterpret_cast<const uint4*>(sbase + (size_t)i * 8);
+        uint4 lo = sp[0], hi = sp[1];
+        const u32 s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        const u32 tb = base_idx[i] * MSM_W;
+        for_each_digit(s, [&](int j, u32 mag, u32 neg) {
+            u32 pos = atomicAdd(&cursor[mag], 1u);
+            sorted[pos] = (tb + (u32)j) | (neg << 31);
+        });
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // D. bucket sums + running-sum fold over this lane's 8 buckets (high to low)
+    ge running = ge_identity(), total = ge_identity();
+    for (int r = MSM_G; r >= 1; r--) {
+        const int k = tid * MSM_G + r;
+        const u32 end = cursor[k];
+        const u32 beg = end - cnt[k];
+        if (beg != end) {
+            ge acc = ge_identity();
+            ge_niels nxt = load_niels(wtable, sorted[beg]);
+            for (u32 e = beg; e < end; e++) {
+                ge_niels cur = nxt;
+                if (e + 1 < end) nxt = load_niels(wtable, sorted[e + 1]);
+                acc = ge_madd(acc, cur);
+            }
+            running = ge_add(running, acc);
+        }
+        total = ge_add(total, running);
+    }
+
+    // E. cross-lane fold: R = sum_t total_t + 8 * sum_{t>=1} suffix_t, suffix_t = sum_{u>=t} running_u
+    lds_put(stage, tid, running);
+    __syncthreads();
+    for (int d = 1; d < MSM_T; d <<= 1) {
+        const bool has = tid + d < MSM_T;
+        ge other = ge_identity();
+        if (has) other = lds_get(stage, tid + d);
+        __syncthreads();
+        if (has) {
+            running = ge_add(running, other);
+            lds_put(stage, tid, running);
+        }
+        __syncthreads();
+    }
+    ge x = total;
+    if (tid >= 1) {
+        ge s = running;
+        for (int i = 0; i < MSM_LOG_G; i++) s = ge_dbl(s);
+        x = ge_add(x, s);
+    }
+    lds_put(stage, tid, x);
+    __syncthreads();
+    for (int d = MSM_T / 2; d >= 1; d >>= 1) {
+        if (tid < d) {
+            ge other = lds_get(stage, tid + d);
+            x = ge_add(x, other);
+            lds_put(stage, tid, x);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) out[msm] = x;
+}
+
+__global__ __launch_bounds__(64) void k_encode(const ge* __restrict__ pts, u32 n, u32* __restrict__ out_words) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    ge p = pts[i];
+    u32 w[8];
+    ge_encode_words(w, p);
+    uint4* o = reinterpret_cast<uint4*>(out_words + (size_t)i * 8);
+    o[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    o[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
+size_t msm_scratch_bytes(uint32_t n_msm, uint32_t n_terms) { return (size_t)n_msm * n_terms * MSM_W * sizeof(u32); }
+
+int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* scalars_dev, const u32* base_idx_dev,
+                   ge* out_points_dev, hipStream_t stream) {
+    if (n_msm == 0) return BBP_OK;
+    if (n_terms == 0 || n_terms > 65535u) {
+        ctx->err = "msm_launch: n_terms out of range";
+        return BBP_ERR_BAD_ARG;
+    }
+    int32_t rc = dev_reserve(ctx, ctx->sorted, msm_scratch_bytes(n_msm, n_terms));
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_msm, dim3(n_msm), dim3(MSM_T), 0, stream, scalars_dev, base_idx_dev, n_terms, ctx->wtable,
+                       (u32*)ctx->sorted.p, out_points_dev);
+    BBP_HIP_TRY(ctx, hipGetLastError());
+    return BBP_OK;
+}
+
+int32_t encode_launch(bbp_ctx* ctx, uint32_t n, const ge* pts_dev, uint8_t* out32_dev, hipStream_t stream) {
+    if (n == 0) return BBP_OK;
+    hipLaunchKernelGGL(k_encode, dim3((n + 63) / 64), dim3(64), 0, stream, pts_dev, n, (u32*)out32_dev);
+    BBP_HIP_TRY(ctx, hipGetLastError());
+    return BBP_OK;
+}
+
+}  // namespace bbp

@@ -1,0 +1,158 @@
+// Context creation: derive the Pedersen / Bulletproof generators and MiMC constants ONCE and keep them
+// resident in HBM, together with the window-shifted affine table the MSM kernels gather from.
+//
+// Replaces generate_cs_transcript()'s per-call `PedersenGens::default()` + `BulletproofGens::new(2048, 1)`
+// (src/blindbid/mod.rs:34-40, re-run by every prove and verify: SURVEY.md F6) and lazy_static CONSTANTS
+// (src/blindbid/mod.rs:7-24).  Hashing (SHA-512 chain, SHAKE256 stream, SHA3-512) is host work; every field /
+// group operation (Elligator maps, doublings, normalisation) runs on the device.
+#include <stdio.h>
+
+#include "context.h"
+#include "hosthash.h"
+
+namespace bbp {
+
+// thread i: uniform[i] (16 LE words) -> gens[dst(i)]
+__global__ void k_derive_generators(const u32* __restrict__ uniform, ge* __restrict__ gens) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > 2 * BBP_GENS_CAPACITY + 1) return;
+    if (i == 2 * BBP_GENS_CAPACITY + 1) {
+        gens[BBP_BASE_B] = ge_basepoint();
+        return;
+    }
+    u32 w[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) w[k] = uniform[(size_t)i * 16 + k];
+    gens[i] = ge_from_uniform_words(w);  // 0: B_blinding, 1..2048: G, 2049..4096: H
+}
+
+// thread i: table[i*W + j] = affine cached form of 2^(C j) * gens[i]
+__global__ void k_build_wtable(const ge* __restrict__ gens, ge_niels* __restrict__ table) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= BBP_NUM_BASES) return;
+    ge p = gens[i];
+    for (int j = 0; j < MSM_W; j++) {
+        table[(size_t)i * MSM_W + j] = ge_to_niels(p, fe_invert(p.Z));
+        for (int k = 0; k < MSM_C; k++) p = ge_dbl(p);
+    }
+}
+
+// radix-16 comb for the two Pedersen bases: comb[b][j][m-1] = m * 16^j * Base_b, m = 1..8, j = 0..63
+__global__ void k_build_comb(const ge* __restrict__ gens, ge_niels* __restrict__ comb) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * 64) return;
+    u32 b = t / 64, j = t % 64;
+    ge p = gens[b == 0 ? BBP_BASE_B : BBP_BASE_BBLIND];
+    for (u32 k = 0; k < 4 * j; k++) p = ge_dbl(p);
+    ge m = p;
+    for (int k = 0; k < 8; k++) {
+        comb[((size_t)b * 64 + j) * 8 + k] = ge_to_niels(m, fe_invert(m.Z));
+        m = ge_add(m, p);
+    }
+}
+
+static void mimc_constants_host(std::vector<uint8_t>& out) {
+    // src/blindbid/mod.rs:7-24: h = SHA512("blind bid"); c_i = wide_reduce(h); h = SHA512(c_i bytes)
+    out.resize(BBP_MIMC_ROUNDS * 32);
+    uint8_t h[64];
+    const uint8_t seed[] = {'b', 'l', 'i', 'n', 'd', ' ', 'b', 'i', 'd'};
+    sha512(seed, sizeof(seed), h);
+    for (int i = 0; i < BBP_MIMC_ROUNDS; i++) {
+        u32 w[16];
+        memcpy(w, h, 64);
+        sc c = sc_from_wide(w);  // integer reduction of a constant: setup plumbing, not the hot path
+        sc_tobytes(&out[32 * i], c);
+        sha512(&out[32 * i], 32, h);
+    }
+}
+
+}  // namespace bbp
+
+using namespace bbp;
+
+extern "C" int32_t bbp_init(int32_t device, bbp_ctx** out) {
+    if (!out) return BBP_ERR_BAD_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        fprintf(stderr, "bbp_init: no usable HIP device (count=%d, requested=%d); this library has no CPU path\n", ndev,
+                device);
+        return BBP_ERR_DEVICE;
+    }
+    bbp_ctx* ctx = new bbp_ctx();
+    ctx->device = device;
+    *out = ctx;  // returned even on failure so bbp_last_error works; caller frees
+    BBP_HIP_TRY(ctx, hipSetDevice(device));
+    hipDeviceProp_t prop;
+    BBP_HIP_TRY(ctx, hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        ctx->err = std::string("bbp_init: device is ") + prop.gcnArchName + ", kernels are built for gfx950 only";
+        return BBP_ERR_DEVICE;
+    }
+    BBP_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+
+    // --- host hashing -----------------------------------------------------------------------------
+    const size_t n_uniform = 2 * BBP_GENS_CAPACITY + 1;
+    std::vector<uint8_t> uniform(n_uniform * 64);
+    // PedersenGens::default(): B_blinding = hash_from_bytes::<Sha3_512>(compress(B))
+    static const uint8_t B_ENC[32] = {0xe2, 0xf2, 0xae, 0x0a, 0x6a, 0xbc, 0x4e, 0x71, 0xa8, 0x84, 0xa9, 0x61, 0xc5, 0x00, 0x51, 0x5f,
+                                      0x58, 0xe3, 0x0b, 0x6a, 0xa5, 0x82, 0xdd, 0x8d, 0xb6, 0xa6, 0x59, 0x45, 0xe0, 0x8d, 0x2d, 0x76};
+    sha3_512(B_ENC, 32, &uniform[0]);
+    // BulletproofGens::new(2048, 1): GeneratorsChain = SHAKE256("GeneratorsChain" || label), label = 'G'/'H' || u32_le(0)
+    for (int which = 0; which < 2; which++) {
+        uint8_t seed[20] = {'G', 'e', 'n', 'e', 'r', 'a', 't', 'o', 'r', 's', 'C', 'h', 'a', 'i', 'n', (uint8_t)(which ? 'H' : 'G'), 0, 0, 0, 0};
+        shake256(seed, 20, &uniform[64 * (1 + (size_t)which * BBP_GENS_CAPACITY)], 64 * BBP_GENS_CAPACITY);
+    }
+    mimc_constants_host(ctx->mimc_host);
+
+    // --- device tables ----------------------------------------------------------------------------
+    u32* d_uniform = nullptr;
+    BBP_HIP_TRY(ctx, hipMalloc(&d_uniform, uniform.size()));
+    BBP_HIP_TRY(ctx, hipMemcpyAsync(d_uniform, uniform.data(), uniform.size(), hipMemcpyHostToDevice, ctx->stream));
+    BBP_HIP_TRY(ctx, hipMalloc(&ctx->gens, sizeof(ge) * BBP_NUM_BASES));
+    BBP_HIP_TRY(ctx, hipMalloc(&ctx->wtable, sizeof(ge_niels) * (size_t)BBP_NUM_BASES * MSM_W));
+    BBP_HIP_TRY(ctx, hipMalloc(&ctx->comb, sizeof(ge_niels) * 2 * 64 * 8));
+    BBP_HIP_TRY(ctx, hipMalloc(&ctx->mimc_c, sizeof(sc) * BBP_MIMC_ROUNDS));
+    BBP_HIP_TRY(ctx, hipMemcpyAsync(ctx->mimc_c, ctx->mimc_host.data(), 32 * BBP_MIMC_ROUNDS, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_derive_generators, dim3((BBP_NUM_BASES + 63) / 64), dim3(64), 0, ctx->stream, d_uniform, ctx->gens);
+    BBP_HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_build_wtable, dim3((BBP_NUM_BASES + 63) / 64), dim3(64), 0, ctx->stream, ctx->gens, ctx->wtable);
+    BBP_HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_build_comb, dim3(2), dim3(64), 0, ctx->stream, ctx->gens, ctx->comb);
+    BBP_HIP_TRY(ctx, hipGetLastError());
+    BBP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    BBP_HIP_TRY(ctx, hipFree(d_uniform));
+    return BBP_OK;
+}
+
+extern "C" void bbp_free(bbp_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    void* ptrs[] = {ctx->gens, ctx->wtable, ctx->comb, ctx->mimc_c, ctx->scal.p, ctx->idx.p, ctx->sorted.p, ctx->pts.p, ctx->enc.p, ctx->misc.p};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" const char* bbp_last_error(const bbp_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" int32_t bbp_get_generator(bbp_ctx* ctx, uint32_t index, uint8_t out32[32]) {
+    if (!ctx || index >= BBP_NUM_BASES) return BBP_ERR_BAD_ARG;
+    BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int32_t rc = dev_reserve(ctx, ctx->enc, 32);
+    if (rc) return rc;
+    rc = encode_launch(ctx, 1, ctx->gens + index, (uint8_t*)ctx->enc.p, ctx->stream);
+    if (rc) return rc;
+    BBP_HIP_TRY(ctx, hipMemcpyAsync(out32, ctx->enc.p, 32, hipMemcpyDeviceToHost, ctx->stream));
+    BBP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return BBP_OK;
+}
+
+extern "C" int32_t bbp_get_mimc_constant(bbp_ctx* ctx, uint32_t i, uint8_t out32[32]) {
+    if (!ctx || i >= BBP_MIMC_ROUNDS) return BBP_ERR_BAD_ARG;
+    BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    BBP_HIP_TRY(ctx, hipMemcpy(out32, ctx->mimc_c + i, 32, hipMemcpyDeviceToHost));  // read back from the device copy
+    return BBP_OK;
+}

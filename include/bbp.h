@@ -1,0 +1,105 @@
+/* bbp.h -- C ABI of the MI355X blind-bid Bulletproofs engine (libbbp_hip.so).
+ *
+ * The reference (dusk-network/dusk-blindbidproof) has no FFI layer of its own: its hot path sits behind two
+ * `pub` Rust functions and two IPC opcodes.  Each entry point below names the reference interface it replaces;
+ * INTEGRATION.md shows the Rust `extern "C"` binding a maintainer would add in src/blindbid/{proof,verify}.rs.
+ *
+ * Conventions: all scalars are 32-byte little-endian; points are 32-byte ristretto255 encodings; every buffer is
+ * caller-owned host memory unless the name ends in `_dev`; functions return a bbp_status; nothing throws or
+ * aborts across this boundary (the reference builds with panic='abort', Cargo.toml:29 -- see SURVEY.md 5).
+ * The library has NO CPU compute path: bbp_init fails with BBP_ERR_DEVICE when no gfx950 device is usable.
+ */
+#ifndef BBP_H
+#define BBP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bbp_ctx bbp_ctx;
+
+typedef enum {
+    BBP_OK = 0,
+    BBP_ERR_VERIFY = 1,    /* R1CSError::VerificationError (src/error.rs:22 via bulletproofs)            */
+    BBP_ERR_GENS_LEN = 2,  /* R1CSError::InvalidGeneratorsLength: N > 202 needs > 2048 multipliers       */
+    BBP_ERR_FORMAT = 3,    /* R1CSError::FormatError / Error::Io(InvalidData|UnexpectedEof) (error.rs)    */
+    BBP_ERR_BAD_ARG = 4,   /* N == 0 or toggle >= N: the reference panics (src/gadgets.rs:103) or proves garbage */
+    BBP_ERR_DEVICE = 5     /* HIP failure / no device                                                     */
+} bbp_status;
+
+#define BBP_MIMC_ROUNDS 90      /* src/gadgets.rs:4 */
+#define BBP_GENS_CAPACITY 2048  /* src/blindbid/mod.rs:36 */
+#define BBP_MAX_ITEMS 202       /* 1442 + 3N <= 2048 */
+#define BBP_R1CS_PROOF_BYTES 1121 /* 1-phase compact R1CSProof::to_bytes */
+
+/* Base-table indices for bbp_msm_batch layouts (device generator table order). */
+#define BBP_BASE_BBLIND 0u /* PedersenGens::B_blinding */
+#define BBP_BASE_G0 1u     /* BulletproofGens G[0..2048) */
+#define BBP_BASE_H0 2049u  /* BulletproofGens H[0..2048) */
+#define BBP_BASE_B 4097u   /* PedersenGens::B (ristretto basepoint) */
+#define BBP_NUM_BASES 4098u
+
+/* Layout ids for bbp_msm_batch. */
+#define BBP_LAYOUT_BLIND_G_H 0u /* terms: B_blinding, G[0..m), H[0..m); n_terms = 1 + 2m  (A_I1, S1)   */
+#define BBP_LAYOUT_BLIND_G 1u   /* terms: B_blinding, G[0..m);          n_terms = 1 + m   (A_O1)       */
+
+/* Replaces generate_cs_transcript()'s per-call generator derivation (src/blindbid/mod.rs:34-40) and the
+ * lazy_static CONSTANTS (src/blindbid/mod.rs:7-24): derives them ONCE on `device` and keeps them resident.
+ * `device` is a HIP device ordinal (one context per GPU / per rank). */
+int32_t bbp_init(int32_t device, bbp_ctx** out);
+void bbp_free(bbp_ctx* ctx);
+const char* bbp_last_error(const bbp_ctx* ctx);
+
+/* Setup read-back for parity tests: compressed generator `index` (table order above) / MiMC constant i. */
+int32_t bbp_get_generator(bbp_ctx* ctx, uint32_t index, uint8_t out32[32]);
+int32_t bbp_get_mimc_constant(bbp_ctx* ctx, uint32_t i, uint8_t out32[32]);
+
+/* Kernel-level hook (BASELINE.json configs[1]): B independent multiscalar multiplications over the shared
+ * generator table; what bulletproofs' Prover::prove does with RistrettoPoint::multiscalar_mul for
+ * A_I1 / A_O1 / S1 (reached from src/blindbid/proof.rs:88).  scalars: B * n_terms * 32 bytes, canonical (< l).
+ * out32: B * 32 bytes, compressed results. */
+int32_t bbp_msm_batch(bbp_ctx* ctx, uint32_t B, uint32_t n_terms, const uint8_t* scalars, uint32_t layout,
+                      uint8_t* out32);
+
+/* Device-resident variant used by bench.py so the timed region starts with inputs in HBM: same semantics with
+ * `scalars_dev` / `out32_dev` being device pointers; `stream` is a hipStream_t (0 = context stream); does not
+ * synchronise.  bbp_msm_workspace_bytes() tells the caller how much scratch bbp_msm_batch_dev will use. */
+int32_t bbp_msm_batch_dev(bbp_ctx* ctx, uint32_t B, uint32_t n_terms, const void* scalars_dev, uint32_t layout,
+                          void* out32_dev, void* stream);
+
+/* Witness helper: what the Go caller computes upstream of Proof::prove (defined by src/gadgets.rs:20-33,70-86):
+ * m = mimc(k,0), x = mimc(d,m), y = mimc(seed,x), z_img = mimc(seed,m), y_inv = 1/y, q = d*y_inv.  Batched on
+ * the device.  in: B * 96 bytes (d,k,seed); out: B * 192 bytes (m,x,y,y_inv,q,z_img). */
+int32_t bbp_witness_batch(bbp_ctx* ctx, uint32_t B, const uint8_t* dks, uint8_t* out);
+
+/* Replaces Proof::prove (src/blindbid/proof.rs:36-46).
+ * scalars7 = d,k,y,y_inv,q,z_img,seed; pub_list = N*32 bytes (Scalar::from_bits semantics, src/blindbid/bid.rs:27);
+ * entropy = (4+N)*32 bytes of commitment blindings + 32 bytes rng seed (replaces thread_rng, proof.rs:53-64), or NULL
+ * to draw from the OS.  proof_out record = R1CSProof bytes || 4*32 commitments || N*32 t_c;
+ * *proof_len receives the R1CSProof byte count (1121). */
+int32_t bbp_prove(bbp_ctx* ctx, const uint8_t scalars7[7 * 32], const uint8_t* pub_list, uint32_t N, uint64_t toggle,
+                  const uint8_t* entropy, uint8_t* proof_out, uint32_t* proof_len);
+uint32_t bbp_proof_record_size(uint32_t N); /* 1121 + 32*(4+N) */
+uint32_t bbp_entropy_size(uint32_t N);      /* 32*(4+N) + 32 */
+
+/* Replaces Verify::new(..).verify() (src/blindbid/verify.rs:27-89). record layout as produced by bbp_prove. */
+int32_t bbp_verify(bbp_ctx* ctx, const uint8_t* record, uint32_t record_len, const uint8_t score[32],
+                   const uint8_t z_img[32], const uint8_t seed[32], const uint8_t* pub_list, uint32_t N);
+
+/* The data-parallel path: B independent proofs with a common list length N, fixed-stride records.
+ * in:  B * (7*32 + N*32 + 8) bytes: scalars7 || pub_list || toggle(u64 LE)
+ * entropy: B * bbp_entropy_size(N) or NULL.  out: B * bbp_proof_record_size(N).  status: B entries. */
+int32_t bbp_prove_batch(bbp_ctx* ctx, uint32_t B, uint32_t N, const uint8_t* in, const uint8_t* entropy,
+                        uint8_t* out, int32_t* status);
+/* in: B * (record_size(N) + 3*32 + N*32): record || score || z_img || seed || pub_list.  status: B entries
+ * (BBP_OK / BBP_ERR_VERIFY / BBP_ERR_FORMAT). */
+int32_t bbp_verify_batch(bbp_ctx* ctx, uint32_t B, uint32_t N, const uint8_t* in, int32_t* status);
+
+/* Per-phase device timings of the last batch call, microseconds (HIP events on the context stream). */
+int32_t bbp_last_timings(bbp_ctx* ctx, float* out, uint32_t cap, uint32_t* n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,46 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def built():
+    """Make sure every native artefact exists (idempotent; no-op when the prebuilt files travelled with the repo)."""
+    import __graft_entry__ as ge
+    ge.build_hip()
+    ge.build_oracle()
+    ge.build_hostcheck()
+    return ge
+
+
+@pytest.fixture(scope="session")
+def bbp(built):
+    import dusk_blindbidproof_amd as m
+    return m
+
+
+@pytest.fixture(scope="session")
+def ctx(bbp):
+    c = bbp.Context(0)  # raises loudly without a gfx950 device: no fallback
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import json
+
+    def load(name):
+        with open(os.path.join(GOLDEN, name)) as f:
+            return json.load(f)
+    return load

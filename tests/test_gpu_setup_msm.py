@@ -1,0 +1,102 @@
+"""GPU parity: resident generator/constant tables and the batched Pippenger MSM (K1) against the big-int oracle.
+All calls go through the C-ABI (include/bbp.h)."""
+import hashlib
+import random
+
+import pytest
+
+from oracle.ref_py import blindbid as bb, ristretto as rs
+
+pytestmark = pytest.mark.gpu
+L = rs.L
+
+
+def test_generators_match_golden(ctx, bbp, golden):
+    kat = golden("setup_kat.json")
+    assert ctx.generator(bbp.BASE_B).hex() == kat["B"]
+    assert ctx.generator(bbp.BASE_BBLIND).hex() == kat["B_blinding"]
+    for i in range(3):
+        assert ctx.generator(bbp.BASE_G0 + i).hex() == kat["G"][i]
+        assert ctx.generator(bbp.BASE_H0 + i).hex() == kat["H"][i]
+    assert ctx.generator(bbp.BASE_G0 + 2047).hex() == kat["G_last"]
+    assert ctx.generator(bbp.BASE_H0 + 2047).hex() == kat["H_last"]
+    g = hashlib.sha256(b"".join(ctx.generator(bbp.BASE_G0 + i) for i in range(2048))).hexdigest()
+    h = hashlib.sha256(b"".join(ctx.generator(bbp.BASE_H0 + i) for i in range(2048))).hexdigest()
+    assert g == kat["G_sha256"] and h == kat["H_sha256"]
+
+
+def test_mimc_constants_match_golden(ctx, golden):
+    kat = golden("setup_kat.json")
+    got = [ctx.mimc_constant(i).hex() for i in range(90)]
+    assert got == kat["mimc_c"]
+    # reference recipe, src/blindbid/mod.rs:7-24, recomputed with hashlib
+    assert got == [rs.sc_bytes(c).hex() for c in bb.mimc_constants()]
+
+
+def _bases(layout, n_terms, bbp):
+    pc, bp = bb.gens(2048)
+    if layout == bbp.LAYOUT_BLIND_G_H:
+        m = (n_terms - 1) // 2
+        return [pc.B_blinding] + bp.G[:m] + bp.H[:m]
+    return [pc.B_blinding] + bp.G[:n_terms - 1]
+
+
+def _edge_scalars():
+    return [0, 1, 2, L - 1, L - 2, 2**252, 2**252 - 1, 1024, 1025, 2047, 2048, (1 << 11) - 1, 1 << 242, (1 << 253) % L,
+            sum(1024 << (11 * j) for j in range(23)) % L, sum(1025 << (11 * j) for j in range(22)) % L]
+
+
+@pytest.mark.parametrize("layout_name,n_terms,B", [("gh", 1 + 2 * 24, 5), ("g", 1 + 33, 4), ("gh", 3, 3), ("g", 1, 2)])
+def test_msm_small_vs_oracle(ctx, bbp, layout_name, n_terms, B):
+    layout = bbp.LAYOUT_BLIND_G_H if layout_name == "gh" else bbp.LAYOUT_BLIND_G
+    rnd = random.Random(n_terms * 131 + B)
+    bases = _bases(layout, n_terms, bbp)
+    edge = _edge_scalars()
+    sc = [[(edge[(i + 7 * b) % len(edge)] if (i + b) % 3 == 0 else rnd.randrange(L)) for i in range(n_terms)] for b in range(B)]
+    sc[0] = [0] * n_terms  # all-zero MSM -> identity
+    buf = b"".join(rs.sc_bytes(s) for row in sc for s in row)
+    out = ctx.msm_batch(B, n_terms, buf, layout)
+    for b in range(B):
+        assert out[32 * b:32 * b + 32] == rs.encode(rs.msm(sc[b], bases)), b
+    assert out[:32] == bytes(32)
+
+
+def test_msm_rejects_noncanonical(ctx, bbp):
+    buf = (L).to_bytes(32, "little") * 3
+    with pytest.raises(bbp.BbpError) as e:
+        ctx.msm_batch(1, 3, buf, bbp.LAYOUT_BLIND_G_H)
+    assert e.value.status == 3
+
+
+@pytest.mark.parametrize("layout_name,n_terms", [("gh", 2933), ("g", 1467), ("gh", 4097)])
+def test_msm_full_size_vs_oracle(ctx, bbp, layout_name, n_terms):
+    """BASELINE.json configs[1] shapes (N = 8: 2933 / 1467 terms) plus the table's maximum width."""
+    layout = bbp.LAYOUT_BLIND_G_H if layout_name == "gh" else bbp.LAYOUT_BLIND_G
+    B = 3
+    bases = _bases(layout, n_terms, bbp)
+    sc = [[rs.sc_wide(hashlib.sha512(b"msm%d/%d/%d" % (n_terms, b, i)).digest()) for i in range(n_terms)] for b in range(B)]
+    # witness-like row: mostly small / boolean scalars
+    sc[1] = [(i % 2) if i % 5 else sc[1][i] for i in range(n_terms)]
+    buf = b"".join(rs.sc_bytes(s) for row in sc for s in row)
+    out = ctx.msm_batch(B, n_terms, buf, layout)
+    for b in range(B):
+        assert out[32 * b:32 * b + 32] == rs.encode(rs.msm(sc[b], bases)), b
+
+
+def test_msm_linearity_large_batch(ctx, bbp):
+    """Size-independent property at batch scale: MSM(s + t) == MSM(s) + MSM(t) for 256 MSMs of 2933 terms."""
+    n_terms, B = 2933, 256
+    rnd = random.Random(99)
+    s = [rnd.randrange(L) for _ in range(n_terms)]
+    rows, exp_rows = [], []
+    for b in range(B):
+        t = [(x * (b + 1) + b) % L for x in s]
+        rows.append(t)
+    buf = b"".join(rs.sc_bytes(v) for row in rows for v in row)
+    out = ctx.msm_batch(B, n_terms, buf, bbp.LAYOUT_BLIND_G_H)
+    pts = [rs.decode(out[32 * b:32 * b + 32]) for b in range(B)]
+    assert all(p is not None for p in pts)
+    # rows[b] = (b+1)*s + b*1  =>  P_b = (b+1)*P_s + b*P_1 ;  check P_b - P_{b-1} is constant (= P_s + P_1)
+    d0 = rs.pt_add(pts[1], rs.pt_neg(pts[0]))
+    for b in range(2, B):
+        assert rs.pt_eq(rs.pt_add(pts[b], rs.pt_neg(pts[b - 1])), d0), b
