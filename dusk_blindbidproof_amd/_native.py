@@ -27,6 +27,7 @@ SIGNATURES = {
     "bbp_verify": (_i32, [_vp, _vp, _u32, _vp, _vp, _vp, _vp, _u32]),
     "bbp_prove_batch": (_i32, [_vp, _u32, _u32, _vp, _vp, _vp, _vp]),
     "bbp_verify_batch": (_i32, [_vp, _u32, _u32, _vp, _vp]),
+    "bbp_set_profiling": (_i32, [_vp, _i32]),
     "bbp_last_timings": (_i32, [_vp, _vp, _u32, ctypes.POINTER(_u32)]),
 }
 
@@ -148,8 +149,12 @@ class Context:
         self._check(lib.bbp_verify_batch(self._h, B, N, _buf(inputs), status))
         return list(status)
 
-    def last_timings(self):
-        arr = (ctypes.c_float * 64)()
+    def set_profiling(self, on):
+        self._check(lib.bbp_set_profiling(self._h, 1 if on else 0))
+
+    def last_timings(self, cap=1 << 16):
+        """[(tag, microseconds)] for every kernel launched since the last drain (profiling must be on)."""
+        arr = (ctypes.c_float * cap)()
         n = ctypes.c_uint32()
-        lib.bbp_last_timings(self._h, arr, 64, ctypes.byref(n))
-        return list(arr)[:n.value]
+        self._check(lib.bbp_last_timings(self._h, arr, cap, ctypes.byref(n)))
+        return [(int(arr[i]), float(arr[i + 1])) for i in range(0, n.value, 2)]

@@ -41,6 +41,13 @@ struct bbp_ctx {
     // grow-only scratch
     bbp::DevBuf scal, idx, sorted, pts, enc, misc;
     std::vector<float> timings;
+    // optional per-kernel HIP-event timing (bbp_set_profiling): (tag, start, stop) on the launch stream
+    bool profile = false;
+    struct Ev {
+        int tag;
+        hipEvent_t a, b;
+    };
+    std::vector<Ev> events;
 };
 
 namespace bbp {
@@ -64,6 +71,27 @@ inline int32_t dev_reserve(bbp_ctx* ctx, DevBuf& b, size_t bytes) {
     b.cap = want;
     return BBP_OK;
 }
+
+enum { TAG_MSM = 1, TAG_ENCODE = 2, TAG_WITNESS = 3, TAG_RNG = 4, TAG_POLY = 5, TAG_IPA_SCALARS = 6, TAG_COMMIT = 7,
+       TAG_TRANSCRIPT = 8, TAG_VERIFY_SCALARS = 9, TAG_VARBASE = 10 };
+
+struct ScopedEvent {  // records start now, stop at scope exit, when profiling is on
+    bbp_ctx* ctx;
+    hipStream_t s;
+    int idx = -1;
+    ScopedEvent(bbp_ctx* c, int tag, hipStream_t st) : ctx(c), s(st) {
+        if (!c->profile) return;
+        bbp_ctx::Ev e;
+        e.tag = tag;
+        if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
+        (void)hipEventRecord(e.a, st);
+        c->events.push_back(e);
+        idx = (int)c->events.size() - 1;
+    }
+    ~ScopedEvent() {
+        if (idx >= 0) (void)hipEventRecord(ctx->events[idx].b, s);
+    }
+};
 
 // msm.hip
 int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* scalars_dev, const u32* base_idx_dev,

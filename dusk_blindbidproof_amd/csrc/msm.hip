@@ -205,6 +205,7 @@ int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* sc
     }
     int32_t rc = dev_reserve(ctx, ctx->sorted, msm_scratch_bytes(n_msm, n_terms));
     if (rc) return rc;
+    ScopedEvent ev(ctx, TAG_MSM, stream);
     hipLaunchKernelGGL(k_msm, dim3(n_msm), dim3(MSM_T), 0, stream, scalars_dev, base_idx_dev, n_terms, ctx->wtable,
                        (u32*)ctx->sorted.p, out_points_dev);
     BBP_HIP_TRY(ctx, hipGetLastError());
@@ -213,6 +214,7 @@ int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* sc
 
 int32_t encode_launch(bbp_ctx* ctx, uint32_t n, const ge* pts_dev, uint8_t* out32_dev, hipStream_t stream) {
     if (n == 0) return BBP_OK;
+    ScopedEvent ev(ctx, TAG_ENCODE, stream);
     hipLaunchKernelGGL(k_encode, dim3((n + 63) / 64), dim3(64), 0, stream, pts_dev, n, (u32*)out32_dev);
     BBP_HIP_TRY(ctx, hipGetLastError());
     return BBP_OK;

@@ -96,7 +96,10 @@ int32_t bbp_prove_batch(bbp_ctx* ctx, uint32_t B, uint32_t N, const uint8_t* in,
  * (BBP_OK / BBP_ERR_VERIFY / BBP_ERR_FORMAT). */
 int32_t bbp_verify_batch(bbp_ctx* ctx, uint32_t B, uint32_t N, const uint8_t* in, int32_t* status);
 
-/* Per-phase device timings of the last batch call, microseconds (HIP events on the context stream). */
+/* Per-kernel device timings: with profiling on, every kernel launch is bracketed by HIP events on its launch stream.
+ * bbp_last_timings synchronises, drains them as (tag, microseconds) float pairs (tags: 1 = MSM kernel, 2 = encode, ...)
+ * and reports the number of floats written in *n. */
+int32_t bbp_set_profiling(bbp_ctx* ctx, int32_t on);
 int32_t bbp_last_timings(bbp_ctx* ctx, float* out, uint32_t cap, uint32_t* n);
 
 #ifdef __cplusplus
