@@ -27,6 +27,9 @@ SIGNATURES = {
     "bbp_verify": (_i32, [_vp, _vp, _u32, _vp, _vp, _vp, _vp, _u32]),
     "bbp_prove_batch": (_i32, [_vp, _u32, _u32, _vp, _vp, _vp, _vp]),
     "bbp_verify_batch": (_i32, [_vp, _u32, _u32, _vp, _vp]),
+    "bbp_prove_batch_dev": (_i32, [_vp, _u32, _u32, _vp, _vp, _vp, _vp]),
+    "bbp_verify_batch_dev": (_i32, [_vp, _u32, _u32, _vp, _vp, _vp, _vp]),
+    "bbp_debug_challenges": (_i32, [_vp, _u32, _u32, _u32, _vp]),
     "bbp_set_profiling": (_i32, [_vp, _i32]),
     "bbp_last_timings": (_i32, [_vp, _vp, _u32, ctypes.POINTER(_u32)]),
 }
@@ -148,6 +151,20 @@ class Context:
         status = (ctypes.c_int32 * B)()
         self._check(lib.bbp_verify_batch(self._h, B, N, _buf(inputs), status))
         return list(status)
+
+    def prove_batch_dev(self, B, N, in_ptr, ent_ptr, out_ptr, stream=0):
+        self._check(lib.bbp_prove_batch_dev(self._h, B, N, in_ptr, ent_ptr, out_ptr, stream))
+
+    def verify_batch_dev(self, B, N, in_ptr, ent_ptr, status_ptr, stream=0):
+        self._check(lib.bbp_verify_batch_dev(self._h, B, N, in_ptr, ent_ptr, status_ptr, stream))
+
+    def debug_challenges(self, B, N, proof):
+        out = (ctypes.c_uint8 * (32 * 32))()
+        self._check(lib.bbp_debug_challenges(self._h, B, N, proof, out))
+        raw = bytes(out)
+        names = ["y", "z", "u", "x", "w", "y_inv", "t1", "t2", "t3", "t4", "t5", "t6", "tb1", "tb2", "tb3", "tb4", "tb5", "tb6",
+                 "t_x", "t_x_blinding", "e_blinding", "uj", "uji", "a", "b", "r", "allinv", "wc", "delta"]
+        return {n: raw[32 * i:32 * i + 32].hex() for i, n in enumerate(names)}
 
     def set_profiling(self, on):
         self._check(lib.bbp_set_profiling(self._h, 1 if on else 0))

@@ -1,22 +1,252 @@
-// C-ABI: prove / verify entry points -- see include/bbp.h.  (Filled in incrementally; NOT_YET paths return BBP_ERR_DEVICE.)
-#include "context.h"
+// C-ABI: prove / verify / witness entry points -- see include/bbp.h for the reference interface each replaces.
+#include <stdio.h>
+#include <string.h>
+
+#include "batch.h"
+
+namespace bbp {
+int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* ent_dev, u8* out_dev, hipStream_t s);
+int32_t verify_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* ent_dev, int32_t* status_dev, hipStream_t s);
+int32_t debug_read_misc(bbp_ctx* ctx, u32 B, u32 N, u32 proof, uint8_t* out);
+
+// native (non-circuit) image of the gadget wiring: what the reference's Go caller computes before Proof::prove
+// (src/gadgets.rs:20-33 for m,x,y,z; :70-86 for y_inv and q)
+__device__ sc mimc_native(sc x, const sc& key, const sc* __restrict__ c) {
+    for (int i = 0; i < BBP_MIMC_ROUNDS; i++) {
+        sc a = sc_add(sc_add(x, key), ld_sc(&c[i]));
+        sc a2 = sc_mul(a, a), a3 = sc_mul(a2, a), a4 = sc_mul(a2, a2);
+        x = sc_mul(a4, a3);
+    }
+    return sc_add(x, key);
+}
+
+__global__ void k_witness_native(u32 B, const u8* __restrict__ dks, const sc* __restrict__ mimc, u8* __restrict__ out) {
+    u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= B) return;
+    const u32* in = reinterpret_cast<const u32*>(dks + 96 * (size_t)p);
+    sc d = sc_reduce256(in), k = sc_reduce256(in + 8), seed = sc_reduce256(in + 16);
+    sc m = mimc_native(k, sc_zero(), mimc);
+    sc x = mimc_native(d, m, mimc);
+    sc y = mimc_native(seed, x, mimc);
+    sc z = mimc_native(seed, m, mimc);
+    sc yi = sc_invert(y);
+    sc q = sc_mul(d, yi);
+    sc* o = reinterpret_cast<sc*>(out + 192 * (size_t)p);
+    st_sc(&o[0], m);
+    st_sc(&o[1], x);
+    st_sc(&o[2], y);
+    st_sc(&o[3], yi);
+    st_sc(&o[4], q);
+    st_sc(&o[5], z);
+}
+
+static bool os_random(uint8_t* buf, size_t n) {
+    FILE* f = fopen("/dev/urandom", "rb");
+    if (!f) return false;
+    size_t got = fread(buf, 1, n, f);
+    fclose(f);
+    return got == n;
+}
+
+}  // namespace bbp
 
 using namespace bbp;
-
-#define NOT_YET(ctx, name)                                  \
-    do {                                                    \
-        if (ctx) (ctx)->err = name ": not implemented yet"; \
-        return BBP_ERR_DEVICE;                              \
-    } while (0)
 
 extern "C" uint32_t bbp_proof_record_size(uint32_t N) { return BBP_R1CS_PROOF_BYTES + 32u * (4u + N); }
 extern "C" uint32_t bbp_entropy_size(uint32_t N) { return 32u * (4u + N) + 32u; }
 
-extern "C" int32_t bbp_witness_batch(bbp_ctx* ctx, uint32_t, const uint8_t*, uint8_t*) { NOT_YET(ctx, "bbp_witness_batch"); }
-extern "C" int32_t bbp_prove(bbp_ctx* ctx, const uint8_t*, const uint8_t*, uint32_t, uint64_t, const uint8_t*, uint8_t*, uint32_t*) { NOT_YET(ctx, "bbp_prove"); }
-extern "C" int32_t bbp_verify(bbp_ctx* ctx, const uint8_t*, uint32_t, const uint8_t*, const uint8_t*, const uint8_t*, const uint8_t*, uint32_t) { NOT_YET(ctx, "bbp_verify"); }
-extern "C" int32_t bbp_prove_batch(bbp_ctx* ctx, uint32_t, uint32_t, const uint8_t*, const uint8_t*, uint8_t*, int32_t*) { NOT_YET(ctx, "bbp_prove_batch"); }
-extern "C" int32_t bbp_verify_batch(bbp_ctx* ctx, uint32_t, uint32_t, const uint8_t*, int32_t*) { NOT_YET(ctx, "bbp_verify_batch"); }
+extern "C" int32_t bbp_witness_batch(bbp_ctx* ctx, uint32_t B, const uint8_t* dks, uint8_t* out) {
+    if (!ctx || !dks || !out) return BBP_ERR_BAD_ARG;
+    if (B == 0) return BBP_OK;
+    BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int32_t rc;
+    if ((rc = dev_reserve(ctx, ctx->io_in, 96 * (size_t)B)) || (rc = dev_reserve(ctx, ctx->io_out, 192 * (size_t)B))) return rc;
+    BBP_HIP_TRY(ctx, hipMemcpyAsync(ctx->io_in.p, dks, 96 * (size_t)B, hipMemcpyHostToDevice, ctx->stream));
+    {
+        ScopedEvent ev(ctx, TAG_WITNESS, ctx->stream);
+        hipLaunchKernelGGL(k_witness_native, dim3((B + 63) / 64), dim3(64), 0, ctx->stream, B, (const u8*)ctx->io_in.p, ctx->mimc_c,
+                           (u8*)ctx->io_out.p);
+        BBP_HIP_TRY(ctx, hipGetLastError());
+    }
+    BBP_HIP_TRY(ctx, hipMemcpyAsync(out, ctx->io_out.p, 192 * (size_t)B, hipMemcpyDeviceToHost, ctx->stream));
+    BBP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return BBP_OK;
+}
+
+static int32_t check_n(bbp_ctx* ctx, uint32_t N) {
+    if (N == 0) {
+        ctx->err = "empty bid list (the reference panics at src/gadgets.rs:103)";
+        return BBP_ERR_BAD_ARG;
+    }
+    if (N > BBP_MAX_ITEMS) {
+        ctx->err = "bid list needs more than 2048 multipliers (R1CSError::InvalidGeneratorsLength)";
+        return BBP_ERR_GENS_LEN;
+    }
+    return BBP_OK;
+}
+
+extern "C" int32_t bbp_prove_batch(bbp_ctx* ctx, uint32_t B, uint32_t N, const uint8_t* in, const uint8_t* entropy, uint8_t* out,
+                                   int32_t* status) {
+    if (!ctx || !in || !out || !status) return BBP_ERR_BAD_ARG;
+    int32_t rc = check_n(ctx, N);
+    if (rc) return rc;
+    if (B == 0) return BBP_OK;
+    BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t in_stride = 7 * 32 + (size_t)N * 32 + 8, ent_stride = bbp_entropy_size(N), out_stride = bbp_proof_record_size(N);
+    // host-side argument screening (the reference's typed API cannot express these states: SURVEY.md 8b)
+    std::vector<uint8_t> fixed;
+    for (uint32_t i = 0; i < B; i++) {
+        const uint8_t* r = in + in_stride * i;
+        status[i] = BBP_OK;
+        uint64_t toggle;
+        memcpy(&toggle, r + 7 * 32 + (size_t)N * 32, 8);
+        if (toggle >= N) status[i] = BBP_ERR_BAD_ARG;
+        for (int k = 0; k < 7 && status[i] == BBP_OK; k++) {
+            u32 w[8];
+            memcpy(w, r + 32 * k, 32);
+            if (!sc_is_canonical(w)) status[i] = BBP_ERR_FORMAT;  // serde Scalar deserialisation is canonical-only
+        }
+        if (status[i] != BBP_OK) {
+            if (fixed.empty()) fixed.assign(in, in + in_stride * B);
+            memset(&fixed[in_stride * i], 0, in_stride);  // neutral stand-in so the batch geometry is unchanged
+        }
+    }
+    const uint8_t* src = fixed.empty() ? in : fixed.data();
+    std::vector<uint8_t> ent_host;
+    if (!entropy) {
+        // thread_rng replacement: 64 OS bytes per blinding, wide-reduced like Scalar::random; 32 OS bytes for the rng seed
+        const uint32_t m = 4 + N;
+        std::vector<uint8_t> raw((size_t)B * (64 * m + 32));
+        if (!os_random(raw.data(), raw.size())) {
+            ctx->err = "cannot read /dev/urandom";
+            return BBP_ERR_DEVICE;
+        }
+        ent_host.resize(ent_stride * B);
+        for (uint32_t i = 0; i < B; i++) {
+            const uint8_t* rp = &raw[(size_t)i * (64 * m + 32)];
+            for (uint32_t k = 0; k < m; k++) {
+                u32 w[16];
+                memcpy(w, rp + 64 * k, 64);
+                sc s = sc_from_wide(w);
+                sc_tobytes(&ent_host[ent_stride * i + 32 * k], s);
+            }
+            memcpy(&ent_host[ent_stride * i + 32 * m], rp + 64 * m, 32);
+        }
+        entropy = ent_host.data();
+    }
+    if ((rc = dev_reserve(ctx, ctx->io_in, in_stride * B)) || (rc = dev_reserve(ctx, ctx->io_ent, ent_stride * B)) ||
+        (rc = dev_reserve(ctx, ctx->io_out, out_stride * B)))
+        return rc;
+    BBP_HIP_TRY(ctx, hipMemcpyAsync(ctx->io_in.p, src, in_stride * B, hipMemcpyHostToDevice, ctx->stream));
+    BBP_HIP_TRY(ctx, hipMemcpyAsync(ctx->io_ent.p, entropy, ent_stride * B, hipMemcpyHostToDevice, ctx->stream));
+    BBP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors may go out of scope
+    if ((rc = prove_batch_dev(ctx, B, N, (const u8*)ctx->io_in.p, (const u8*)ctx->io_ent.p, (u8*)ctx->io_out.p, ctx->stream))) return rc;
+    BBP_HIP_TRY(ctx, hipMemcpyAsync(out, ctx->io_out.p, out_stride * B, hipMemcpyDeviceToHost, ctx->stream));
+    BBP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (uint32_t i = 0; i < B; i++)
+        if (status[i] != BBP_OK) memset(out + out_stride * i, 0, out_stride);
+    return BBP_OK;
+}
+
+extern "C" int32_t bbp_prove_batch_dev(bbp_ctx* ctx, uint32_t B, uint32_t N, const void* in_dev, const void* entropy_dev, void* out_dev,
+                                       void* stream) {
+    if (!ctx || !in_dev || !entropy_dev || !out_dev) return BBP_ERR_BAD_ARG;
+    int32_t rc = check_n(ctx, N);
+    if (rc) return rc;
+    if (B == 0) return BBP_OK;
+    BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return prove_batch_dev(ctx, B, N, (const u8*)in_dev, (const u8*)entropy_dev, (u8*)out_dev, stream ? (hipStream_t)stream : ctx->stream);
+}
+
+extern "C" int32_t bbp_prove(bbp_ctx* ctx, const uint8_t scalars7[7 * 32], const uint8_t* pub_list, uint32_t N, uint64_t toggle,
+                             const uint8_t* entropy, uint8_t* proof_out, uint32_t* proof_len) {
+    if (!ctx || !scalars7 || !proof_out) return BBP_ERR_BAD_ARG;
+    int32_t rc = check_n(ctx, N);
+    if (rc) return rc;
+    if (!pub_list) return BBP_ERR_BAD_ARG;
+    std::vector<uint8_t> in(7 * 32 + (size_t)N * 32 + 8);
+    memcpy(&in[0], scalars7, 7 * 32);
+    memcpy(&in[7 * 32], pub_list, (size_t)N * 32);
+    memcpy(&in[7 * 32 + (size_t)N * 32], &toggle, 8);
+    int32_t st = BBP_OK;
+    rc = bbp_prove_batch(ctx, 1, N, in.data(), entropy, proof_out, &st);
+    if (rc) return rc;
+    if (st != BBP_OK) {
+        ctx->err = st == BBP_ERR_BAD_ARG ? "toggle >= N" : "non-canonical scalar input";
+        return st;
+    }
+    if (proof_len) *proof_len = BBP_R1CS_PROOF_BYTES;
+    return BBP_OK;
+}
+
+extern "C" int32_t bbp_verify_batch(bbp_ctx* ctx, uint32_t B, uint32_t N, const uint8_t* in, int32_t* status) {
+    if (!ctx || !in || !status) return BBP_ERR_BAD_ARG;
+    int32_t rc = check_n(ctx, N);
+    if (rc) return rc;
+    if (B == 0) return BBP_OK;
+    BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t stride = (size_t)bbp_proof_record_size(N) + 96 + (size_t)N * 32;
+    std::vector<uint8_t> ent((size_t)B * 32);
+    if (!os_random(ent.data(), ent.size())) {  // Verifier::verify mixes thread_rng into its TranscriptRng (A.7)
+        ctx->err = "cannot read /dev/urandom";
+        return BBP_ERR_DEVICE;
+    }
+    if ((rc = dev_reserve(ctx, ctx->io_in, stride * B)) || (rc = dev_reserve(ctx, ctx->io_ent, 32 * (size_t)B)) ||
+        (rc = dev_reserve(ctx, ctx->io_out, 4 * (size_t)B)))
+        return rc;
+    BBP_HIP_TRY(ctx, hipMemcpyAsync(ctx->io_in.p, in, stride * B, hipMemcpyHostToDevice, ctx->stream));
+    BBP_HIP_TRY(ctx, hipMemcpyAsync(ctx->io_ent.p, ent.data(), ent.size(), hipMemcpyHostToDevice, ctx->stream));
+    BBP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = verify_batch_dev(ctx, B, N, (const u8*)ctx->io_in.p, (const u8*)ctx->io_ent.p, (int32_t*)ctx->io_out.p, ctx->stream))) return rc;
+    BBP_HIP_TRY(ctx, hipMemcpyAsync(status, ctx->io_out.p, 4 * (size_t)B, hipMemcpyDeviceToHost, ctx->stream));
+    BBP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return BBP_OK;
+}
+
+extern "C" int32_t bbp_verify_batch_dev(bbp_ctx* ctx, uint32_t B, uint32_t N, const void* in_dev, const void* entropy_dev,
+                                        void* status_dev, void* stream) {
+    if (!ctx || !in_dev || !entropy_dev || !status_dev) return BBP_ERR_BAD_ARG;
+    int32_t rc = check_n(ctx, N);
+    if (rc) return rc;
+    if (B == 0) return BBP_OK;
+    BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return verify_batch_dev(ctx, B, N, (const u8*)in_dev, (const u8*)entropy_dev, (int32_t*)status_dev,
+                            stream ? (hipStream_t)stream : ctx->stream);
+}
+
+extern "C" int32_t bbp_verify(bbp_ctx* ctx, const uint8_t* record, uint32_t record_len, const uint8_t score[32], const uint8_t z_img[32],
+                              const uint8_t seed[32], const uint8_t* pub_list, uint32_t N) {
+    if (!ctx || !record || !score || !z_img || !seed) return BBP_ERR_BAD_ARG;
+    int32_t rc = check_n(ctx, N);
+    if (rc) return rc;
+    if (!pub_list) return BBP_ERR_BAD_ARG;
+    const uint32_t want = bbp_proof_record_size(N);
+    if (record_len != want) {
+        // R1CSProof::from_bytes: only the 1-phase compact layout (1121 bytes) can belong to this circuit; the 2-phase
+        // layout (1217 bytes) parses in the reference but can never verify for a circuit without randomized constraints
+        // unless A_I2 = A_O2 = S2 = identity, which to_bytes would have emitted in the compact form.
+        ctx->err = "record length does not match R1CSProof(1121) || 32*(4+N)";
+        return BBP_ERR_FORMAT;
+    }
+    std::vector<uint8_t> in((size_t)want + 96 + (size_t)N * 32);
+    memcpy(&in[0], record, want);
+    memcpy(&in[want], score, 32);
+    memcpy(&in[want + 32], z_img, 32);
+    memcpy(&in[want + 64], seed, 32);
+    memcpy(&in[want + 96], pub_list, (size_t)N * 32);
+    int32_t st = BBP_ERR_DEVICE;
+    rc = bbp_verify_batch(ctx, 1, N, in.data(), &st);
+    if (rc) return rc;
+    return st;
+}
+
+extern "C" int32_t bbp_debug_challenges(bbp_ctx* ctx, uint32_t B, uint32_t N, uint32_t proof, uint8_t* out32x32) {
+    if (!ctx || !out32x32 || proof >= B) return BBP_ERR_BAD_ARG;
+    BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    BBP_HIP_TRY(ctx, hipDeviceSynchronize());
+    return debug_read_misc(ctx, B, N, proof, out32x32);
+}
+
 extern "C" int32_t bbp_set_profiling(bbp_ctx* ctx, int32_t on) {
     if (!ctx) return BBP_ERR_BAD_ARG;
     ctx->profile = on != 0;

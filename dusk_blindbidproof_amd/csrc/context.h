@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <map>
 #include <string>
 #include <vector>
 
@@ -39,7 +40,8 @@ struct bbp_ctx {
     uint8_t gens_enc_host_valid = 0;
     std::vector<uint8_t> mimc_host;    // 90 * 32
     // grow-only scratch
-    bbp::DevBuf scal, idx, sorted, pts, enc, misc;
+    bbp::DevBuf scal, idx, sorted, pts, enc, misc, batch, io_in, io_out, io_ent;
+    std::map<uint32_t, void*> circuits;  // N -> CircuitDev* (compiled blind-bid circuit tables on the device)
     std::vector<float> timings;
     // optional per-kernel HIP-event timing (bbp_set_profiling): (tag, start, stop) on the launch stream
     bool profile = false;
@@ -94,8 +96,9 @@ struct ScopedEvent {  // records start now, stop at scope exit, when profiling i
 };
 
 // msm.hip
+// base_idx_dev holds n_idx_sets lists of n_terms indices; MSM number i uses list (i % n_idx_sets)
 int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* scalars_dev, const u32* base_idx_dev,
-                   ge* out_points_dev, hipStream_t stream);
+                   ge* out_points_dev, hipStream_t stream, uint32_t n_idx_sets = 1);
 int32_t encode_launch(bbp_ctx* ctx, uint32_t n, const ge* pts_dev, uint8_t* out32_dev, hipStream_t stream);
 size_t msm_scratch_bytes(uint32_t n_msm, uint32_t n_terms);
 

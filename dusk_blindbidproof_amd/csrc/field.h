@@ -21,6 +21,7 @@
 
 namespace bbp {
 
+typedef uint8_t u8;
 typedef uint32_t u32;
 typedef uint64_t u64;
 

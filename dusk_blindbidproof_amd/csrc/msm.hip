@@ -68,9 +68,9 @@ __device__ __forceinline__ void for_each_digit(const u32 (&s)[8], F&& f) {
     }
 }
 
-__global__ __launch_bounds__(MSM_T) void k_msm(const u32* __restrict__ scalars, const u32* __restrict__ base_idx, u32 n,
-                                                const ge_niels* __restrict__ wtable, u32* __restrict__ sorted_all,
-                                                ge* __restrict__ out) {
+__global__ __launch_bounds__(MSM_T) void k_msm(const u32* __restrict__ scalars, const u32* __restrict__ base_idx_sets, u32 n,
+                                                u32 n_idx_sets, const ge_niels* __restrict__ wtable,
+                                                u32* __restrict__ sorted_all, ge* __restrict__ out) {
     __shared__ u32 cnt[MSM_K + 1];
     __shared__ u32 cursor[MSM_K + 1];
     __shared__ u32 part[MSM_T];
@@ -79,6 +79,7 @@ __global__ __launch_bounds__(MSM_T) void k_msm(const u32* __restrict__ scalars, 
     const size_t msm = blockIdx.x;
     const u32* sbase = scalars + msm * (size_t)n * 8;
     u32* sorted = sorted_all + msm * (size_t)n * MSM_W;
+    const u32* base_idx = base_idx_sets + (size_t)(blockIdx.x % n_idx_sets) * n;
 
     for (int k = tid; k <= MSM_K; k += MSM_T) cnt[k] = 0;
     __syncthreads();
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(64) void k_encode(const ge* __restrict__ pts, u32 n
 size_t msm_scratch_bytes(uint32_t n_msm, uint32_t n_terms) { return (size_t)n_msm * n_terms * MSM_W * sizeof(u32); }
 
 int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* scalars_dev, const u32* base_idx_dev,
-                   ge* out_points_dev, hipStream_t stream) {
+                   ge* out_points_dev, hipStream_t stream, uint32_t n_idx_sets) {
     if (n_msm == 0) return BBP_OK;
     if (n_terms == 0 || n_terms > 65535u) {
         ctx->err = "msm_launch: n_terms out of range";
@@ -206,7 +207,7 @@ int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* sc
     int32_t rc = dev_reserve(ctx, ctx->sorted, msm_scratch_bytes(n_msm, n_terms));
     if (rc) return rc;
     ScopedEvent ev(ctx, TAG_MSM, stream);
-    hipLaunchKernelGGL(k_msm, dim3(n_msm), dim3(MSM_T), 0, stream, scalars_dev, base_idx_dev, n_terms, ctx->wtable,
+    hipLaunchKernelGGL(k_msm, dim3(n_msm), dim3(MSM_T), 0, stream, scalars_dev, base_idx_dev, n_terms, n_idx_sets, ctx->wtable,
                        (u32*)ctx->sorted.p, out_points_dev);
     BBP_HIP_TRY(ctx, hipGetLastError());
     return BBP_OK;

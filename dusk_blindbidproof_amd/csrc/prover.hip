@@ -1,0 +1,779 @@
+// Batched R1CS prover for the blind-bid circuit on gfx950: replaces Proof::prove (src/blindbid/proof.rs:36-91) and the
+// bulletproofs machinery under it (Prover::{new,commit,multiply,constrain,prove}, InnerProductProof::create;
+// SURVEY.md App. A.4-A.6) for a whole batch of independent bids.
+//
+// Pipeline (every stage is a device kernel over the batch; the host only sequences launches):
+//   k_witness      one lane per proof interprets the compiled gadget program -> a_L, a_R, a_O            (K3)
+//   k_commit       V_i = v_i B + vb_i B~ through the radix-16 comb of the two Pedersen bases                (K2)
+//   k_tr_open      Merlin: "V" x m, "m"; TranscriptRng keyed with the blindings; draws i~,o~,s~,s_L,s_R     (K7)
+//   k_msm x3       A_I1, A_O1, S1                                                                            (K1)
+//   k_tr_yz        Merlin: commitments, 1-phase dom-sep, identity A_I2/A_O2/S2, challenges y, z
+//   k_powers       z^k, y^k, y^-k by chunked square-and-multiply
+//   k_flatten      wL, wR, wO, wV = sparse gather of z powers (circuit structure is shared by the batch)   (K4)
+//   k_poly         l1, r0, r1, r3 and the six t coefficients, block reduction in LDS                        (K5)
+//   k_tr_tblind / k_commit / k_tr_ux   T_1,3,4,5,6, challenges u, x, t_x, t_x~, e~, challenge w
+//   k_lrvec        l(x), r(x) and the per-generator factor vectors g[k], h[k]
+//   11 x { k_ipa_round, k_msm (2 per proof), k_encode }                                                      (K6)
+//   k_ipa_final, k_assemble
+//
+// The inner-product argument never folds the generator vectors.  Round j's L and R are multiscalar multiplications
+// over the ORIGINAL resident generators with scalars a[i] * g[k] / b[i] * h[k], where g[k], h[k] accumulate the
+// challenge products u_r^(+-1) that the reference applies by folding G and H (A.6).  The group elements are equal,
+// encodings are canonical, hence identical bytes -- and every MSM of the prover is a fixed-base MSM over one table.
+#include <string.h>
+
+#include "batch.h"
+#include "hosthash.h"
+
+namespace bbp {
+
+// ---------------------------------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sc_to_bytes32(uint8_t* o, const sc& s) { sc_tobytes(o, s); }
+__device__ __forceinline__ void words_to_bytes32(uint8_t* o, const u32* w) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        o[4 * i] = (uint8_t)w[i];
+        o[4 * i + 1] = (uint8_t)(w[i] >> 8);
+        o[4 * i + 2] = (uint8_t)(w[i] >> 16);
+        o[4 * i + 3] = (uint8_t)(w[i] >> 24);
+    }
+}
+__device__ __forceinline__ void bytes_to_words(u32* w, const uint8_t* b, int nwords) {
+    for (int i = 0; i < nwords; i++) w[i] = (u32)b[4 * i] | ((u32)b[4 * i + 1] << 8) | ((u32)b[4 * i + 2] << 16) | ((u32)b[4 * i + 3] << 24);
+}
+
+#define LBL(s) reinterpret_cast<const uint8_t*>(s), (u32)(sizeof(s) - 1)
+
+__device__ void tr_append_words(merlin_transcript& t, const uint8_t* label, u32 llen, const u32* w8) {
+    uint8_t b[32];
+    words_to_bytes32(b, w8);
+    merlin_append(t, label, llen, b, 32);
+}
+__device__ void tr_append_sc(merlin_transcript& t, const uint8_t* label, u32 llen, const sc& s) { tr_append_words(t, label, llen, s.v); }
+__device__ sc tr_challenge_sc(merlin_transcript& t, const uint8_t* label, u32 llen) {
+    uint8_t b[64];
+    merlin_challenge(t, label, llen, b, 64);
+    u32 w[16];
+    bytes_to_words(w, b, 16);
+    return sc_from_wide(w);
+}
+__device__ sc rng_scalar(merlin_transcript& r) {
+    uint8_t b[64];
+    merlin_rng_fill(r, b, 64);
+    u32 w[16];
+    bytes_to_words(w, b, 16);
+    return sc_from_wide(w);
+}
+
+// x^e by square-and-multiply (e < 2^16)
+__device__ sc sc_pow_small(const sc& x, u32 e) {
+    sc xm = sc_to_mont(x), acc = sc_r();
+    for (int i = 15; i >= 0; i--) {
+        acc = sc_montmul(acc, acc);
+        if ((e >> i) & 1u) acc = sc_montmul(acc, xm);
+    }
+    return sc_from_mont(acc);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K3: witness
+// ---------------------------------------------------------------------------------------------------------------
+// in_raw per proof: 7 scalars (d,k,y,y_inv,q,z_img,seed) || N items || toggle(u64)
+__global__ void k_witness(u32 B, u32 n_items, u32 n_mul, u32 n_cst, const u8* __restrict__ in_raw, const u32* __restrict__ w_terms,
+                          const u32* __restrict__ w_loff, const u32* __restrict__ w_roff, sc* __restrict__ cst_all,
+                          sc* __restrict__ v_all, sc* __restrict__ ai1_all, sc* __restrict__ ao1_all, int prover) {
+    u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= B) return;
+    const size_t in_stride = 7 * 32 + (size_t)n_items * 32 + 8;
+    const u32* in = reinterpret_cast<const u32*>(in_raw + in_stride * p);
+    sc* cst = cst_all + (size_t)p * n_cst;
+    const u32 m = 4 + n_items;
+    sc s7[7];
+    for (int i = 0; i < 7; i++) s7[i] = sc_reduce256(in + 8 * i);
+    st_sc(&cst[circuit::CST_ONE], sc_one());
+    st_sc(&cst[circuit::CST_ZERO], sc_zero());
+    st_sc(&cst[circuit::CST_SEED], s7[6]);
+    st_sc(&cst[circuit::CST_ZIMG], s7[5]);
+    st_sc(&cst[circuit::CST_Q], s7[4]);
+    for (u32 i = 0; i < n_items; i++) st_sc(&cst[circuit::CST_ITEM0 + i], sc_from_bits(in + 56 + 8 * i));  // bid.rs:27
+    if (!prover) return;
+    sc* v = v_all + (size_t)p * m;
+    const u32 toggle = in[56 + 8 * n_items];
+    st_sc(&v[0], s7[0]);
+    st_sc(&v[1], s7[1]);
+    st_sc(&v[2], s7[2]);  // y: committed but never wired into the gadget (proof.rs:55, 76-78)
+    st_sc(&v[3], s7[3]);
+    for (u32 i = 0; i < n_items; i++) st_sc(&v[4 + i], i == toggle ? sc_one() : sc_zero());
+    sc* aL = ai1_all + (size_t)p * (1 + 2 * n_mul) + 1;
+    sc* aR = aL + n_mul;
+    sc* aO = ao1_all + (size_t)p * (1 + n_mul) + 1;
+    for (u32 i = 0; i < n_mul; i++) {
+        sc lr[2];
+        const u32 bounds[3] = {w_loff[i], w_roff[i], w_loff[i + 1]};
+        for (int side = 0; side < 2; side++) {
+            sc acc = sc_zero();
+            for (u32 t = bounds[side]; t < bounds[side + 1]; t++) {
+                const u32 w = w_terms[t], kind = w >> 29, idx = w & 0x0fffffffu;
+                const sc* src = kind == 4 ? &cst[idx] : kind == 3 ? &aO[idx] : kind == 1 ? &aL[idx] : kind == 2 ? &aR[idx] : &v[idx];
+                sc val = ld_sc(src);
+                acc = ((w >> 28) & 1u) ? sc_sub(acc, val) : sc_add(acc, val);
+            }
+            lr[side] = acc;
+        }
+        st_sc(&aL[i], lr[0]);
+        st_sc(&aR[i], lr[1]);
+        st_sc(&aO[i], sc_mul(lr[0], lr[1]));
+    }
+}
+
+// MiMC constants into every proof's constant table (one lane per (proof, round))
+__global__ void k_fill_mimc(u32 B, u32 n_cst, const sc* __restrict__ mimc, sc* __restrict__ cst_all) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * BBP_MIMC_ROUNDS) return;
+    u32 p = t / BBP_MIMC_ROUNDS, i = t % BBP_MIMC_ROUNDS;
+    st_sc(&cst_all[(size_t)p * n_cst + circuit::CST_MIMC0 + i], ld_sc(&mimc[i]));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K2: Pedersen commitments through the radix-16 comb (64 signed digits per scalar, 8 cached multiples each)
+// ---------------------------------------------------------------------------------------------------------------
+__device__ ge comb_mul_add(ge acc, const ge_niels* __restrict__ comb_base, const sc& s) {
+    u32 carry = 0;
+    for (int j = 0; j < 64; j++) {
+        u32 d = ((s.v[j >> 3] >> (4 * (j & 7))) & 15u) + carry;
+        carry = d > 8u;
+        u32 mag = carry ? 16u - d : d;
+        if (mag) {
+            const uint4* q = reinterpret_cast<const uint4*>(comb_base + (size_t)j * 8 + (mag - 1));
+            uint4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5];
+            ge_niels n;
+            n.ypx = BBP_FE_LIT(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w);
+            n.ymx = BBP_FE_LIT(q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w);
+            n.xy2d = BBP_FE_LIT(q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w);
+            if (carry) {
+                fe t = n.ypx;
+                n.ypx = n.ymx;
+                n.ymx = t;
+                n.xy2d = fe_neg(n.xy2d);
+            }
+            acc = ge_madd(acc, n);
+        }
+    }
+    return acc;  // canonical scalars are < 2^253: the top digit never carries out
+}
+
+// commitment c of proof p: values[p*stride_v + c], blindings[p*stride_b + c] -> out[p*out_stride + c]
+__global__ void k_commit(u32 count, u32 per_proof, const sc* __restrict__ values, const sc* __restrict__ blindings, u32 stride_v,
+                         u32 stride_b, const ge_niels* __restrict__ comb, ge* __restrict__ out, u32 out_stride) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    u32 p = t / per_proof, c = t % per_proof;
+    sc v = ld_sc(&values[(size_t)p * stride_v + c]);
+    sc b = ld_sc(&blindings[(size_t)p * stride_b + c]);
+    ge acc = comb_mul_add(ge_identity(), comb, v);              // v * B
+    acc = comb_mul_add(acc, comb + 64 * 8, b);                  // + vb * B_blinding
+    out[(size_t)p * out_stride + c] = acc;
+}
+
+int32_t commit_launch(bbp_ctx* ctx, u32 count, const sc* values, const sc* blindings, u32 stride_v, u32 stride_b, u32 per_proof,
+                      ge* out, u32 out_stride, hipStream_t s) {
+    if (!count) return BBP_OK;
+    ScopedEvent ev(ctx, TAG_COMMIT, s);
+    hipLaunchKernelGGL(k_commit, dim3((count + 63) / 64), dim3(64), 0, s, count, per_proof, values, blindings, stride_v, stride_b,
+                       ctx->comb, out, out_stride);
+    BBP_HIP_TRY(ctx, hipGetLastError());
+    return BBP_OK;
+}
+
+// encode `per_proof` points per proof from a strided point array into a strided encoding array
+__global__ void k_encode_strided(u32 count, u32 per_proof, const ge* __restrict__ pts, u32 pts_stride, u32* __restrict__ enc,
+                                 u32 enc_stride_words, u32 enc_off_words) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    u32 p = t / per_proof, c = t % per_proof;
+    u32 w[8];
+    ge_encode_words(w, pts[(size_t)p * pts_stride + c]);
+    u32* o = enc + (size_t)p * enc_stride_words + enc_off_words + 8 * c;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o[i] = w[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K7: transcript stages (one lane per proof)
+// ---------------------------------------------------------------------------------------------------------------
+// enc layout per proof (words): V[m] | A_I1 A_O1 S1 | T_1 T_3 T_4 T_5 T_6 | (L_j R_j) x 11
+__device__ __forceinline__ u32 enc_stride_words(u32 m) { return (m + 8 + 22) * 8; }
+
+__global__ void k_tr_open(u32 B, u32 m, u32 n1, merlin_transcript prefix, const u32* __restrict__ enc, const u8* __restrict__ entropy,
+                          sc* __restrict__ vb_all, sc* __restrict__ ai1, sc* __restrict__ ao1, sc* __restrict__ s1,
+                          merlin_transcript* __restrict__ tr_out, merlin_transcript* __restrict__ rng_out) {
+    u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= B) return;
+    merlin_transcript t = prefix;  // Transcript::new(b"BlindBidProofGadget") + r1cs_domain_sep (A.4)
+    const u32* e = enc + (size_t)p * enc_stride_words(m);
+    for (u32 i = 0; i < m; i++) tr_append_words(t, LBL("V"), e + 8 * i);
+    merlin_append_u64(t, LBL("m"), (u64)m);
+    // TranscriptRng: rekey with every v_blinding in commit order, then 32 bytes of external entropy (A.5 step 2)
+    merlin_transcript r = t;
+    const sc* vb = vb_all + (size_t)p * m;
+    for (u32 i = 0; i < m; i++) {
+        uint8_t b[32];
+        sc_to_bytes32(b, ld_sc(&vb[i]));
+        merlin_rng_rekey(r, LBL("v_blinding"), b, 32);
+    }
+    const u8* ent = entropy + (size_t)p * (32 * (size_t)m + 32) + 32 * (size_t)m;
+    uint8_t seed[32];
+    for (int i = 0; i < 32; i++) seed[i] = ent[i];
+    merlin_rng_finalize(r, seed);
+    sc* a = ai1 + (size_t)p * (1 + 2 * n1);
+    sc* o = ao1 + (size_t)p * (1 + n1);
+    sc* s = s1 + (size_t)p * (1 + 2 * n1);
+    st_sc(&a[0], rng_scalar(r));  // i_blinding1
+    st_sc(&o[0], rng_scalar(r));  // o_blinding1
+    st_sc(&s[0], rng_scalar(r));  // s_blinding1
+    for (u32 i = 0; i < 2 * n1; i++) st_sc(&s[1 + i], rng_scalar(r));  // s_L1 then s_R1
+    tr_out[p] = t;
+    rng_out[p] = r;
+}
+
+// blindings from the entropy block: (4+N) 32-byte values, reduced
+__global__ void k_load_blindings(u32 B, u32 m, const u8* __restrict__ entropy, sc* __restrict__ vb_all) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * m) return;
+    u32 p = t / m, i = t % m;
+    const u32* w = reinterpret_cast<const u32*>(entropy + (size_t)p * (32 * (size_t)m + 32) + 32 * (size_t)i);
+    st_sc(&vb_all[(size_t)p * m + i], sc_reduce256(w));
+}
+
+__global__ void k_tr_yz(u32 B, u32 m, const u32* __restrict__ enc, merlin_transcript* __restrict__ tr, sc* __restrict__ misc) {
+    u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= B) return;
+    merlin_transcript t = tr[p];
+    const u32* e = enc + (size_t)p * enc_stride_words(m) + 8 * m;
+    tr_append_words(t, LBL("A_I1"), e);
+    tr_append_words(t, LBL("A_O1"), e + 8);
+    tr_append_words(t, LBL("S1"), e + 16);
+    merlin_append(t, LBL("dom-sep"), LBL("r1cs-1phase"));  // no randomized constraints in this circuit (A.5 step 5)
+    const u32 ident[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    tr_append_words(t, LBL("A_I2"), ident);
+    tr_append_words(t, LBL("A_O2"), ident);
+    tr_append_words(t, LBL("S2"), ident);
+    sc y = tr_challenge_sc(t, LBL("y"));
+    sc z = tr_challenge_sc(t, LBL("z"));
+    sc* ms = misc + (size_t)p * MS_COUNT;
+    st_sc(&ms[MS_Y], y);
+    st_sc(&ms[MS_Z], z);
+    st_sc(&ms[MS_YINV], sc_invert(y));
+    tr[p] = t;
+}
+
+// out[p][e] = base[p]^e for e in [0, count): one lane per chunk of 32 exponents
+__global__ void k_powers(u32 B, u32 count, const sc* __restrict__ misc, int slot, sc* __restrict__ out, u32 out_stride) {
+    const u32 chunks = (count + 31) / 32;
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * chunks) return;
+    u32 p = t / chunks, c = t % chunks;
+    sc x = ld_sc(&misc[(size_t)p * MS_COUNT + slot]);
+    sc xm = sc_to_mont(x);
+    sc cur = sc_to_mont(sc_pow_small(x, c * 32));
+    sc* o = out + (size_t)p * out_stride;
+    u32 end = min(count, c * 32 + 32);
+    for (u32 e = c * 32; e < end; e++) {
+        st_sc(&o[e], sc_from_mont(cur));
+        cur = sc_montmul(cur, xm);
+    }
+}
+
+// K4: flattened constraint weights.  target t of proof p = sum over its entries of +-z^(q+1)
+__global__ void k_flatten(u32 B, u32 n_tgt, u32 n_mul, u32 m, const u32* __restrict__ f_off, const u32* __restrict__ f_ent,
+                          const sc* __restrict__ zpow, u32 zstride, sc* __restrict__ wl, sc* __restrict__ wr, sc* __restrict__ wo,
+                          sc* __restrict__ wv, u32 wstride) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * n_tgt) return;
+    u32 p = t / n_tgt, k = t % n_tgt;
+    const sc* zp = zpow + (size_t)p * zstride;
+    sc acc = sc_zero();
+    for (u32 e = f_off[k]; e < f_off[k + 1]; e++) {
+        u32 w = f_ent[e];
+        sc zq = ld_sc(&zp[(w & 0x7fffffffu) + 1]);
+        acc = (w >> 31) ? sc_sub(acc, zq) : sc_add(acc, zq);
+    }
+    sc* dst = k < n_mul ? &wl[(size_t)p * wstride + k]
+              : k < 2 * n_mul ? &wr[(size_t)p * wstride + (k - n_mul)]
+              : k < 3 * n_mul ? &wo[(size_t)p * wstride + (k - 2 * n_mul)]
+                              : &wv[(size_t)p * m + (k - 3 * n_mul)];
+    st_sc(dst, acc);
+}
+
+// block-wide sum of NV scalars per lane through LDS (BLK lanes); result valid in lane 0
+template <int NV, int BLK>
+__device__ void block_sum_sc(sc (&vals)[NV], u32* lds /* NV*8*BLK words */) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < NV; k++)
+#pragma unroll
+        for (int w = 0; w < 8; w++) lds[(k * 8 + w) * BLK + tid] = vals[k].v[w];
+    __syncthreads();
+    for (int d = BLK / 2; d >= 1; d >>= 1) {
+        if (tid < d) {
+#pragma unroll
+            for (int k = 0; k < NV; k++) {
+                sc o;
+#pragma unroll
+                for (int w = 0; w < 8; w++) o.v[w] = lds[(k * 8 + w) * BLK + tid + d];
+                vals[k] = sc_add(vals[k], o);
+#pragma unroll
+                for (int w = 0; w < 8; w++) lds[(k * 8 + w) * BLK + tid] = vals[k].v[w];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// K5: l/r polynomial coefficient sweep and the t coefficients (A.5 steps 8-9); one 256-lane block per proof
+constexpr int POLY_BLK = 256;
+__global__ __launch_bounds__(POLY_BLK) void k_poly(u32 n1, const sc* __restrict__ ai1, const sc* __restrict__ ao1, const sc* __restrict__ s1,
+                                                    const sc* __restrict__ wl, const sc* __restrict__ wr, const sc* __restrict__ wo,
+                                                    u32 wstride, const sc* __restrict__ ypow, const sc* __restrict__ yipow,
+                                                    sc* __restrict__ l1o, sc* __restrict__ r0o, sc* __restrict__ r1o, sc* __restrict__ r3o,
+                                                    sc* __restrict__ misc) {
+    __shared__ u32 lds[6 * 8 * POLY_BLK];
+    const u32 p = blockIdx.x;
+    const sc* aL = ai1 + (size_t)p * (1 + 2 * n1) + 1;
+    const sc* aR = aL + n1;
+    const sc* aO = ao1 + (size_t)p * (1 + n1) + 1;
+    const sc* sL = s1 + (size_t)p * (1 + 2 * n1) + 1;
+    const sc* sR = sL + n1;
+    const sc *WL = wl + (size_t)p * wstride, *WR = wr + (size_t)p * wstride, *WO = wo + (size_t)p * wstride;
+    const sc *Y = ypow + (size_t)p * 2049, *YI = yipow + (size_t)p * 2048;
+    sc t[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) t[k] = sc_zero();
+    for (u32 i = threadIdx.x; i < n1; i += POLY_BLK) {
+        sc y = ld_sc(&Y[i]);
+        sc l1 = sc_add(ld_sc(&aL[i]), sc_mul(ld_sc(&YI[i]), ld_sc(&WR[i])));
+        sc l2 = ld_sc(&aO[i]), l3 = ld_sc(&sL[i]);
+        sc r0 = sc_sub(ld_sc(&WO[i]), y);
+        sc r1 = sc_add(sc_mul(y, ld_sc(&aR[i])), ld_sc(&WL[i]));
+        sc r3 = sc_mul(y, ld_sc(&sR[i]));
+        st_sc(&l1o[(size_t)p * n1 + i], l1);
+        st_sc(&r0o[(size_t)p * n1 + i], r0);
+        st_sc(&r1o[(size_t)p * n1 + i], r1);
+        st_sc(&r3o[(size_t)p * n1 + i], r3);
+        t[0] = sc_add(t[0], sc_mul(l1, r0));
+        t[1] = sc_add(t[1], sc_add(sc_mul(l1, r1), sc_mul(l2, r0)));
+        t[2] = sc_add(t[2], sc_add(sc_mul(l2, r1), sc_mul(l3, r0)));
+        t[3] = sc_add(t[3], sc_add(sc_mul(l1, r3), sc_mul(l3, r1)));
+        t[4] = sc_add(t[4], sc_mul(l2, r3));
+        t[5] = sc_add(t[5], sc_mul(l3, r3));
+    }
+    block_sum_sc<6, POLY_BLK>(t, lds);
+    if (threadIdx.x == 0) {
+        sc* ms = misc + (size_t)p * MS_COUNT;
+#pragma unroll
+        for (int k = 0; k < 6; k++) st_sc(&ms[MS_T1 + k], t[k]);
+    }
+}
+
+__global__ void k_tr_tblind(u32 B, merlin_transcript* __restrict__ rng, sc* __restrict__ misc) {
+    u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= B) return;
+    merlin_transcript r = rng[p];
+    sc* ms = misc + (size_t)p * MS_COUNT;
+    st_sc(&ms[MS_TB1], rng_scalar(r));  // t_1, t_3, t_4, t_5, t_6 blindings, in this order (A.5 step 10)
+    st_sc(&ms[MS_TB3], rng_scalar(r));
+    st_sc(&ms[MS_TB4], rng_scalar(r));
+    st_sc(&ms[MS_TB5], rng_scalar(r));
+    st_sc(&ms[MS_TB6], rng_scalar(r));
+    rng[p] = r;
+}
+
+// T_k = t_k B + tb_k B~ for k in {1,3,4,5,6}: one lane per (proof, k)
+__global__ void k_commit_T(u32 B, const sc* __restrict__ misc, const ge_niels* __restrict__ comb, ge* __restrict__ pts, u32 pts_stride, u32 m) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * 5) return;
+    u32 p = t / 5, k = t % 5;
+    const int slot[5] = {0, 2, 3, 4, 5};
+    const sc* ms = misc + (size_t)p * MS_COUNT;
+    ge acc = comb_mul_add(ge_identity(), comb, ld_sc(&ms[MS_T1 + slot[k]]));
+    acc = comb_mul_add(acc, comb + 64 * 8, ld_sc(&ms[MS_TB1 + slot[k]]));
+    pts[(size_t)p * pts_stride + m + 3 + k] = acc;
+}
+
+__global__ void k_tr_ux(u32 B, u32 m, u32 n1, const u32* __restrict__ enc, const sc* __restrict__ wv, const sc* __restrict__ vb,
+                        const sc* __restrict__ ai1, const sc* __restrict__ ao1, const sc* __restrict__ s1,
+                        merlin_transcript* __restrict__ tr, sc* __restrict__ misc) {
+    u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= B) return;
+    merlin_transcript t = tr[p];
+    const u32* e = enc + (size_t)p * enc_stride_words(m) + 8 * (m + 3);
+    tr_append_words(t, LBL("T_1"), e);
+    tr_append_words(t, LBL("T_3"), e + 8);
+    tr_append_words(t, LBL("T_4"), e + 16);
+    tr_append_words(t, LBL("T_5"), e + 24);
+    tr_append_words(t, LBL("T_6"), e + 32);
+    sc u = tr_challenge_sc(t, LBL("u"));
+    sc x = tr_challenge_sc(t, LBL("x"));
+    sc* ms = misc + (size_t)p * MS_COUNT;
+    sc tb2 = sc_zero();  // t_2_blinding = <wV, v_blinding> (A.5 step 12)
+    for (u32 i = 0; i < m; i++) tb2 = sc_add(tb2, sc_mul(ld_sc(&wv[(size_t)p * m + i]), ld_sc(&vb[(size_t)p * m + i])));
+    st_sc(&ms[MS_TB2], tb2);
+    sc t_x = sc_zero(), t_xb = sc_zero(), xp = x;
+    for (int k = 0; k < 6; k++) {
+        t_x = sc_add(t_x, sc_mul(ld_sc(&ms[MS_T1 + k]), xp));
+        t_xb = sc_add(t_xb, sc_mul(ld_sc(&ms[MS_TB1 + k]), xp));
+        xp = sc_mul(xp, x);
+    }
+    sc ib = ld_sc(&ai1[(size_t)p * (1 + 2 * n1)]), ob = ld_sc(&ao1[(size_t)p * (1 + n1)]), sb = ld_sc(&s1[(size_t)p * (1 + 2 * n1)]);
+    sc e_bl = sc_mul(x, sc_add(ib, sc_mul(x, sc_add(ob, sc_mul(x, sb)))));  // phase-2 blindings are zero (A.5 step 14)
+    tr_append_sc(t, LBL("t_x"), t_x);
+    tr_append_sc(t, LBL("t_x_blinding"), t_xb);
+    tr_append_sc(t, LBL("e_blinding"), e_bl);
+    sc w = tr_challenge_sc(t, LBL("w"));
+    // InnerProductProof::create opens with its domain separator (A.6)
+    merlin_append(t, LBL("dom-sep"), LBL("ipp v1"));
+    merlin_append_u64(t, LBL("n"), 2048);
+    st_sc(&ms[MS_U], u);
+    st_sc(&ms[MS_X], x);
+    st_sc(&ms[MS_W], w);
+    st_sc(&ms[MS_TX], t_x);
+    st_sc(&ms[MS_TXB], t_xb);
+    st_sc(&ms[MS_EBL], e_bl);
+    tr[p] = t;
+}
+
+// l(x), r(x) (A.5 step 13) and the generator factor vectors g[k] = G_factors[k], h[k] = y^-k G_factors[k] (step 16)
+__global__ void k_lrvec(u32 B, u32 n1, const sc* __restrict__ l1, const sc* __restrict__ r0, const sc* __restrict__ r1, const sc* __restrict__ r3,
+                        const sc* __restrict__ ao1, const sc* __restrict__ s1, const sc* __restrict__ ypow, const sc* __restrict__ yipow,
+                        const sc* __restrict__ misc, sc* __restrict__ a, sc* __restrict__ b, sc* __restrict__ g, sc* __restrict__ h) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * 2048) return;
+    u32 p = t >> 11, i = t & 2047;
+    const sc* ms = misc + (size_t)p * MS_COUNT;
+    sc x = ld_sc(&ms[MS_X]);
+    sc av, bv, gv;
+    if (i < n1) {
+        sc x2 = sc_mul(x, x), x3 = sc_mul(x2, x);
+        sc l2 = ld_sc(&ao1[(size_t)p * (1 + n1) + 1 + i]), l3 = ld_sc(&s1[(size_t)p * (1 + 2 * n1) + 1 + i]);
+        av = sc_add(sc_add(sc_mul(ld_sc(&l1[(size_t)p * n1 + i]), x), sc_mul(l2, x2)), sc_mul(l3, x3));
+        bv = sc_add(sc_add(ld_sc(&r0[(size_t)p * n1 + i]), sc_mul(ld_sc(&r1[(size_t)p * n1 + i]), x)), sc_mul(ld_sc(&r3[(size_t)p * n1 + i]), x3));
+        gv = sc_one();
+    } else {
+        av = sc_zero();
+        bv = sc_neg(ld_sc(&ypow[(size_t)p * 2049 + i]));
+        gv = ld_sc(&ms[MS_U]);
+    }
+    st_sc(&a[(size_t)p * 2048 + i], av);
+    st_sc(&b[(size_t)p * 2048 + i], bv);
+    st_sc(&g[(size_t)p * 2048 + i], gv);
+    st_sc(&h[(size_t)p * 2048 + i], sc_mul(ld_sc(&yipow[(size_t)p * 2048 + i]), gv));
+}
+
+// K6: one inner-product round.  n = half length of THIS round (1024 >> (round-1)).
+//   round > 1: lane 0 first absorbs the previous L, R, draws u, inverts it; everyone folds a, b and updates g, h.
+//   then: c_L, c_R and the scalars of this round's L and R over the ORIGINAL generators.
+constexpr int IPA_BLK = 256;
+__global__ __launch_bounds__(IPA_BLK) void k_ipa_round(u32 round, u32 m, const u32* __restrict__ enc, merlin_transcript* __restrict__ tr,
+                                                        sc* __restrict__ misc, sc* __restrict__ a_all, sc* __restrict__ b_all,
+                                                        sc* __restrict__ g_all, sc* __restrict__ h_all, sc* __restrict__ lr_all) {
+    __shared__ u32 lds[2 * 8 * IPA_BLK];
+    __shared__ u32 bc[16];
+    const u32 p = blockIdx.x, tid = threadIdx.x;
+    sc* ms = misc + (size_t)p * MS_COUNT;
+    sc *a = a_all + (size_t)p * 2048, *b = b_all + (size_t)p * 2048, *g = g_all + (size_t)p * 2048, *h = h_all + (size_t)p * 2048;
+    const u32 n = 1024u >> (round - 1);
+    if (round > 1) {
+        if (tid == 0) {
+            merlin_transcript t = tr[p];
+            const u32* e = enc + (size_t)p * enc_stride_words(m) + 8 * (m + 8) + 16 * (round - 2);
+            tr_append_words(t, LBL("L"), e);
+            tr_append_words(t, LBL("R"), e + 8);
+            sc u = tr_challenge_sc(t, LBL("u"));
+            sc ui = sc_invert(u);
+            tr[p] = t;
+#pragma unroll
+            for (int w = 0; w < 8; w++) {
+                bc[w] = u.v[w];
+                bc[8 + w] = ui.v[w];
+            }
+        }
+        __syncthreads();
+        sc u, ui;
+#pragma unroll
+        for (int w = 0; w < 8; w++) {
+            u.v[w] = bc[w];
+            ui.v[w] = bc[8 + w];
+        }
+        const u32 n2 = 2 * n;  // half length of the previous round = current full length
+        // fold a, b: a'[i] = a[i] u + u^-1 a[n2+i] ; b'[i] = b[i] u^-1 + u b[n2+i]
+        for (u32 i = tid; i < n2; i += IPA_BLK) {
+            sc alo = ld_sc(&a[i]), ahi = ld_sc(&a[n2 + i]), blo = ld_sc(&b[i]), bhi = ld_sc(&b[n2 + i]);
+            st_sc(&a[i], sc_add(sc_mul(alo, u), sc_mul(ui, ahi)));
+            st_sc(&b[i], sc_add(sc_mul(blo, ui), sc_mul(u, bhi)));
+        }
+        // generator factors: low half of each 2*n2 block took u^-1 (G) / u (H); high half the opposite
+        for (u32 k = tid; k < 2048; k += IPA_BLK) {
+            bool hi = (k & (2 * n2 - 1)) >= n2;
+            st_sc(&g[k], sc_mul(ld_sc(&g[k]), hi ? u : ui));
+            st_sc(&h[k], sc_mul(ld_sc(&h[k]), hi ? ui : u));
+        }
+        __syncthreads();
+    }
+    // scalars of L and R; c_L = <a_lo, b_hi>, c_R = <a_hi, b_lo>
+    sc* L = lr_all + (size_t)p * 2 * 2049;
+    sc* R = L + 2049;
+    sc c[2] = {sc_zero(), sc_zero()};
+    for (u32 k = tid; k < 2048; k += IPA_BLK) {
+        const u32 i = k & (2 * n - 1), blk = k / (2 * n);
+        const bool hi = i >= n;
+        const u32 io = hi ? i - n : i, rank = blk * n + io;
+        sc gk = ld_sc(&g[k]), hk = ld_sc(&h[k]);
+        if (hi) {
+            st_sc(&L[rank], sc_mul(ld_sc(&a[io]), gk));            // a_L[io] * G_R
+            st_sc(&R[1024 + rank], sc_mul(ld_sc(&b[io]), hk));     // b_L[io] * H_R
+        } else {
+            st_sc(&R[rank], sc_mul(ld_sc(&a[n + io]), gk));        // a_R[io] * G_L
+            st_sc(&L[1024 + rank], sc_mul(ld_sc(&b[n + io]), hk)); // b_R[io] * H_L
+        }
+    }
+    for (u32 i = tid; i < n; i += IPA_BLK) {
+        sc alo = ld_sc(&a[i]), ahi = ld_sc(&a[n + i]), blo = ld_sc(&b[i]), bhi = ld_sc(&b[n + i]);
+        c[0] = sc_add(c[0], sc_mul(alo, bhi));
+        c[1] = sc_add(c[1], sc_mul(ahi, blo));
+    }
+    block_sum_sc<2, IPA_BLK>(c, lds);
+    if (tid == 0) {
+        sc w = ld_sc(&ms[MS_W]);  // Q = w B, so c * Q = (c w) B
+        st_sc(&L[2048], sc_mul(c[0], w));
+        st_sc(&R[2048], sc_mul(c[1], w));
+    }
+}
+
+__global__ void k_ipa_final(u32 B, u32 m, const u32* __restrict__ enc, merlin_transcript* __restrict__ tr, sc* __restrict__ misc,
+                            const sc* __restrict__ a_all, const sc* __restrict__ b_all) {
+    u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= B) return;
+    merlin_transcript t = tr[p];
+    const u32* e = enc + (size_t)p * enc_stride_words(m) + 8 * (m + 8) + 16 * 10;
+    tr_append_words(t, LBL("L"), e);
+    tr_append_words(t, LBL("R"), e + 8);
+    sc u = tr_challenge_sc(t, LBL("u"));
+    sc ui = sc_invert(u);
+    const sc *a = a_all + (size_t)p * 2048, *b = b_all + (size_t)p * 2048;
+    sc* ms = misc + (size_t)p * MS_COUNT;
+    st_sc(&ms[MS_A0], sc_add(sc_mul(ld_sc(&a[0]), u), sc_mul(ui, ld_sc(&a[1]))));
+    st_sc(&ms[MS_B0], sc_add(sc_mul(ld_sc(&b[0]), ui), sc_mul(u, ld_sc(&b[1]))));
+    tr[p] = t;
+}
+
+// record = R1CSProof::to_bytes (1-phase compact form, A.8) || V[0..4) || V[4..m)
+__global__ void k_assemble(u32 B, u32 m, const u32* __restrict__ enc, const sc* __restrict__ misc, u8* __restrict__ out) {
+    u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= B) return;
+    const u32* e = enc + (size_t)p * enc_stride_words(m);
+    const sc* ms = misc + (size_t)p * MS_COUNT;
+    u8* o = out + (size_t)p * (BBP_R1CS_PROOF_BYTES + 32 * (size_t)m);
+    *o++ = 0;  // ONE_PHASE_COMMITMENTS
+    auto put = [&](const u32* w) {
+        words_to_bytes32(o, w);
+        o += 32;
+    };
+    for (u32 i = 0; i < 8; i++) put(e + 8 * (m + i));  // A_I1 A_O1 S1 T_1 T_3 T_4 T_5 T_6
+    sc s;
+    s = ld_sc(&ms[MS_TX]); put(s.v);
+    s = ld_sc(&ms[MS_TXB]); put(s.v);
+    s = ld_sc(&ms[MS_EBL]); put(s.v);
+    for (u32 j = 0; j < 22; j++) put(e + 8 * (m + 8 + j));  // L_1 R_1 ... L_11 R_11
+    s = ld_sc(&ms[MS_A0]); put(s.v);
+    s = ld_sc(&ms[MS_B0]); put(s.v);
+    for (u32 i = 0; i < m; i++) put(e + 8 * i);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side: circuit cache, batch buffers, orchestration
+// ---------------------------------------------------------------------------------------------------------------
+template <class T>
+static int32_t upload(bbp_ctx* ctx, const std::vector<T>& v, T** out) {
+    *out = nullptr;
+    if (v.empty()) return BBP_OK;
+    BBP_HIP_TRY(ctx, hipMalloc(out, v.size() * sizeof(T)));
+    BBP_HIP_TRY(ctx, hipMemcpy(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return BBP_OK;
+}
+
+int32_t circuit_get(bbp_ctx* ctx, uint32_t n_items, const CircuitDev** out) {
+    auto it = ctx->circuits.find(n_items);
+    if (it != ctx->circuits.end()) {
+        *out = static_cast<const CircuitDev*>(it->second);
+        return BBP_OK;
+    }
+    circuit::Compiled c = circuit::compile(n_items);
+    if (c.padded != 2048) {
+        ctx->err = "circuit does not pad to 2048 multipliers";
+        return BBP_ERR_GENS_LEN;
+    }
+    CircuitDev* d = new CircuitDev();
+    d->n_items = n_items;
+    d->m = c.m;
+    d->n_mul = c.n_mul;
+    d->n_cons = c.n_cons;
+    d->padded = c.padded;
+    d->n_cst = circuit::cst_count(n_items);
+    d->n_cterms = (u32)c.c_q.size();
+    int32_t rc;
+    if ((rc = upload(ctx, c.w_terms, &d->w_terms)) || (rc = upload(ctx, c.w_loff, &d->w_loff)) || (rc = upload(ctx, c.w_roff, &d->w_roff)) ||
+        (rc = upload(ctx, c.f_off, &d->f_off)) || (rc = upload(ctx, c.f_ent, &d->f_ent)) || (rc = upload(ctx, c.c_q, &d->c_q)) ||
+        (rc = upload(ctx, c.c_cst, &d->c_cst)))
+        return rc;
+    std::vector<u32> ai, ao, ipa, ver;
+    ai.push_back(BBP_BASE_BBLIND);
+    ao.push_back(BBP_BASE_BBLIND);
+    for (u32 i = 0; i < c.n_mul; i++) ai.push_back(BBP_BASE_G0 + i), ao.push_back(BBP_BASE_G0 + i);
+    for (u32 i = 0; i < c.n_mul; i++) ai.push_back(BBP_BASE_H0 + i);
+    // IPA round r (1-based), n = 1024 >> (r-1): term rank = blk*n + io of block blk = k / 2n
+    for (u32 r = 1; r <= 11; r++) {
+        const u32 n = 1024u >> (r - 1);
+        std::vector<u32> L(2049), R(2049);
+        for (u32 rank = 0; rank < 1024; rank++) {
+            u32 blk = rank / n, io = rank % n;
+            u32 k_lo = blk * 2 * n + io, k_hi = k_lo + n;
+            L[rank] = BBP_BASE_G0 + k_hi;
+            L[1024 + rank] = BBP_BASE_H0 + k_lo;
+            R[rank] = BBP_BASE_G0 + k_lo;
+            R[1024 + rank] = BBP_BASE_H0 + k_hi;
+        }
+        L[2048] = R[2048] = BBP_BASE_B;
+        ipa.insert(ipa.end(), L.begin(), L.end());
+        ipa.insert(ipa.end(), R.begin(), R.end());
+    }
+    for (u32 i = 0; i < 2048; i++) ver.push_back(BBP_BASE_G0 + i);
+    for (u32 i = 0; i < 2048; i++) ver.push_back(BBP_BASE_H0 + i);
+    ver.push_back(BBP_BASE_B);
+    ver.push_back(BBP_BASE_BBLIND);
+    if ((rc = upload(ctx, ai, &d->idx_ai)) || (rc = upload(ctx, ao, &d->idx_ao)) || (rc = upload(ctx, ipa, &d->idx_ipa)) ||
+        (rc = upload(ctx, ver, &d->idx_ver)))
+        return rc;
+    ctx->circuits[n_items] = d;
+    *out = d;
+    return BBP_OK;
+}
+
+int32_t batch_reserve(bbp_ctx* ctx, uint32_t B, const CircuitDev& c, BatchDev& bd) {
+    const size_t n1 = c.n_mul, m = c.m;
+    size_t off = 0;
+    auto take = [&](size_t bytes_per_proof) {
+        size_t o = off;
+        off += ((bytes_per_proof * B + 255) / 256) * 256;
+        return o;
+    };
+    const size_t S = sizeof(sc);
+    size_t o_cst = take(c.n_cst * S), o_v = take(m * S), o_vb = take(m * S), o_ai1 = take((1 + 2 * n1) * S), o_ao1 = take((1 + n1) * S),
+           o_s1 = take((1 + 2 * n1) * S), o_tr = take(sizeof(merlin_transcript)), o_rng = take(sizeof(merlin_transcript)),
+           o_misc = take(MS_COUNT * S), o_zpow = take(((size_t)c.n_cons + 1) * S), o_ypow = take(2049 * S), o_yipow = take(2048 * S),
+           o_wl = take(2048 * S), o_wr = take(2048 * S), o_wo = take(2048 * S), o_wv = take(m * S), o_l1 = take(n1 * S), o_r0 = take(n1 * S),
+           o_r1 = take(n1 * S), o_r3 = take(n1 * S), o_a = take(2048 * S), o_b = take(2048 * S), o_g = take(2048 * S), o_h = take(2048 * S),
+           o_lr = take(2 * 2049 * S), o_pts = take((m + 8) * sizeof(ge)), o_lrpts = take(2 * sizeof(ge)),
+           o_enc = take((m + 8 + 22) * 32), o_ent = take(32 * m + 32);
+    int32_t rc = dev_reserve(ctx, ctx->batch, off);
+    if (rc) return rc;
+    u8* base = static_cast<u8*>(ctx->batch.p);
+    bd.B = B;
+    bd.n_items = c.n_items;
+    bd.m = c.m;
+    bd.n1 = c.n_mul;
+    bd.n_cons = c.n_cons;
+    bd.cst = (sc*)(base + o_cst); bd.v = (sc*)(base + o_v); bd.vb = (sc*)(base + o_vb); bd.ai1 = (sc*)(base + o_ai1);
+    bd.ao1 = (sc*)(base + o_ao1); bd.s1 = (sc*)(base + o_s1); bd.tr = (merlin_transcript*)(base + o_tr);
+    bd.rng = (merlin_transcript*)(base + o_rng); bd.misc = (sc*)(base + o_misc); bd.zpow = (sc*)(base + o_zpow);
+    bd.ypow = (sc*)(base + o_ypow); bd.yipow = (sc*)(base + o_yipow); bd.wl = (sc*)(base + o_wl); bd.wr = (sc*)(base + o_wr);
+    bd.wo = (sc*)(base + o_wo); bd.wv = (sc*)(base + o_wv); bd.l1 = (sc*)(base + o_l1); bd.r0 = (sc*)(base + o_r0);
+    bd.r1 = (sc*)(base + o_r1); bd.r3 = (sc*)(base + o_r3); bd.a = (sc*)(base + o_a); bd.b = (sc*)(base + o_b); bd.g = (sc*)(base + o_g);
+    bd.h = (sc*)(base + o_h); bd.lr = (sc*)(base + o_lr); bd.pts = (ge*)(base + o_pts); bd.lrpts = (ge*)(base + o_lrpts);
+    bd.enc = (u32*)(base + o_enc); bd.entropy = base + o_ent;
+    return BBP_OK;
+}
+
+static merlin_transcript prover_prefix() {
+    // Transcript::new(b"BlindBidProofGadget") (src/blindbid/mod.rs:37) then Prover::new / Verifier::new's r1cs_domain_sep (A.4)
+    merlin_transcript t;
+    merlin_init(t, reinterpret_cast<const uint8_t*>("BlindBidProofGadget"), 19);
+    merlin_append(t, reinterpret_cast<const uint8_t*>("dom-sep"), 7, reinterpret_cast<const uint8_t*>("r1cs v1"), 7);
+    return t;
+}
+
+#define LAUNCH(ctx, tag, kern, grid, block, stream, ...)                             \
+    do {                                                                             \
+        ScopedEvent _ev(ctx, tag, stream);                                           \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, stream, __VA_ARGS__);   \
+        BBP_HIP_TRY(ctx, hipGetLastError());                                         \
+    } while (0)
+
+static inline u32 cdiv(u32 a, u32 b) { return (a + b - 1) / b; }
+
+// in_dev: B * (7*32 + N*32 + 8) ; ent_dev: B * (32 m + 32) ; out_dev: B * (1121 + 32 m).  All device pointers.
+int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* ent_dev, u8* out_dev, hipStream_t s) {
+    const CircuitDev* cp;
+    int32_t rc = circuit_get(ctx, N, &cp);
+    if (rc) return rc;
+    const CircuitDev& c = *cp;
+    BatchDev bd;
+    if ((rc = batch_reserve(ctx, B, c, bd))) return rc;
+    const u32 m = c.m, n1 = c.n_mul, encw = (m + 8 + 22) * 8;
+    const merlin_transcript prefix = prover_prefix();
+
+    LAUNCH(ctx, TAG_WITNESS, k_fill_mimc, cdiv(B * BBP_MIMC_ROUNDS, 64), 64, s, B, c.n_cst, ctx->mimc_c, bd.cst);
+    LAUNCH(ctx, TAG_WITNESS, k_witness, cdiv(B, 64), 64, s, B, N, n1, c.n_cst, in_dev, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v, bd.ai1,
+           bd.ao1, 1);
+    LAUNCH(ctx, TAG_TRANSCRIPT, k_load_blindings, cdiv(B * m, 64), 64, s, B, m, ent_dev, bd.vb);
+    if ((rc = commit_launch(ctx, B * m, bd.v, bd.vb, m, m, m, bd.pts, m + 8, s))) return rc;
+    LAUNCH(ctx, TAG_ENCODE, k_encode_strided, cdiv(B * m, 64), 64, s, B * m, m, bd.pts, m + 8, bd.enc, encw, 0u);
+    LAUNCH(ctx, TAG_RNG, k_tr_open, cdiv(B, 64), 64, s, B, m, n1, prefix, bd.enc, ent_dev, bd.vb, bd.ai1, bd.ao1, bd.s1, bd.tr, bd.rng);
+    // A_I1, A_O1, S1 -> pts[m + 0..2] (strided output: launch per commitment with an output view)
+    if ((rc = dev_reserve(ctx, ctx->pts, sizeof(ge) * (size_t)B * 3))) return rc;
+    ge* tmp = static_cast<ge*>(ctx->pts.p);
+    if ((rc = msm_launch(ctx, B, 1 + 2 * n1, (const u32*)bd.ai1, c.idx_ai, tmp, s))) return rc;
+    if ((rc = msm_launch(ctx, B, 1 + n1, (const u32*)bd.ao1, c.idx_ao, tmp + B, s))) return rc;
+    if ((rc = msm_launch(ctx, B, 1 + 2 * n1, (const u32*)bd.s1, c.idx_ai, tmp + 2 * (size_t)B, s))) return rc;
+    for (u32 k = 0; k < 3; k++)
+        LAUNCH(ctx, TAG_ENCODE, k_encode_strided, cdiv(B, 64), 64, s, B, 1u, tmp + (size_t)k * B, 1u, bd.enc, encw, 8 * (m + k));
+    LAUNCH(ctx, TAG_TRANSCRIPT, k_tr_yz, cdiv(B, 64), 64, s, B, m, bd.enc, bd.tr, bd.misc);
+    LAUNCH(ctx, TAG_POLY, k_powers, cdiv(B * cdiv(c.n_cons + 1, 32), 64), 64, s, B, c.n_cons + 1, bd.misc, (int)MS_Z, bd.zpow, c.n_cons + 1);
+    LAUNCH(ctx, TAG_POLY, k_powers, cdiv(B * cdiv(2049, 32), 64), 64, s, B, 2049u, bd.misc, (int)MS_Y, bd.ypow, 2049u);
+    LAUNCH(ctx, TAG_POLY, k_powers, cdiv(B * cdiv(2048, 32), 64), 64, s, B, 2048u, bd.misc, (int)MS_YINV, bd.yipow, 2048u);
+    const u32 n_tgt = 3 * n1 + m;
+    LAUNCH(ctx, TAG_POLY, k_flatten, cdiv(B * n_tgt, 128), 128, s, B, n_tgt, n1, m, c.f_off, c.f_ent, bd.zpow, c.n_cons + 1, bd.wl, bd.wr,
+           bd.wo, bd.wv, 2048u);
+    LAUNCH(ctx, TAG_POLY, k_poly, B, POLY_BLK, s, n1, bd.ai1, bd.ao1, bd.s1, bd.wl, bd.wr, bd.wo, 2048u, bd.ypow, bd.yipow, bd.l1, bd.r0,
+           bd.r1, bd.r3, bd.misc);
+    LAUNCH(ctx, TAG_TRANSCRIPT, k_tr_tblind, cdiv(B, 64), 64, s, B, bd.rng, bd.misc);
+    LAUNCH(ctx, TAG_COMMIT, k_commit_T, cdiv(B * 5, 64), 64, s, B, bd.misc, ctx->comb, bd.pts, m + 8, m);
+    LAUNCH(ctx, TAG_ENCODE, k_encode_strided, cdiv(B * 5, 64), 64, s, B * 5, 5u, bd.pts + (m + 3), m + 8, bd.enc, encw, 8 * (m + 3));
+    LAUNCH(ctx, TAG_TRANSCRIPT, k_tr_ux, cdiv(B, 64), 64, s, B, m, n1, bd.enc, bd.wv, bd.vb, bd.ai1, bd.ao1, bd.s1, bd.tr, bd.misc);
+    LAUNCH(ctx, TAG_POLY, k_lrvec, cdiv(B * 2048, 128), 128, s, B, n1, bd.l1, bd.r0, bd.r1, bd.r3, bd.ao1, bd.s1, bd.ypow, bd.yipow, bd.misc,
+           bd.a, bd.b, bd.g, bd.h);
+    for (u32 r = 1; r <= 11; r++) {
+        LAUNCH(ctx, TAG_IPA_SCALARS, k_ipa_round, B, IPA_BLK, s, r, m, bd.enc, bd.tr, bd.misc, bd.a, bd.b, bd.g, bd.h, bd.lr);
+        if ((rc = msm_launch(ctx, 2 * B, 2049, (const u32*)bd.lr, c.idx_ipa + (size_t)(r - 1) * 2 * 2049, bd.lrpts, s, 2))) return rc;
+        LAUNCH(ctx, TAG_ENCODE, k_encode_strided, cdiv(2 * B, 64), 64, s, 2 * B, 2u, bd.lrpts, 2u, bd.enc, encw, 8 * (m + 8 + 2 * (r - 1)));
+    }
+    LAUNCH(ctx, TAG_TRANSCRIPT, k_ipa_final, cdiv(B, 64), 64, s, B, m, bd.enc, bd.tr, bd.misc, bd.a, bd.b);
+    LAUNCH(ctx, TAG_TRANSCRIPT, k_assemble, cdiv(B, 64), 64, s, B, m, bd.enc, bd.misc, out_dev);
+    return BBP_OK;
+}
+
+// debug / parity hook: copy a proof's challenge block (MS_COUNT scalars) to the host
+int32_t debug_read_misc(bbp_ctx* ctx, u32 B, u32 N, u32 proof, uint8_t* out) {
+    const CircuitDev* cp;
+    int32_t rc = circuit_get(ctx, N, &cp);
+    if (rc) return rc;
+    BatchDev bd;
+    if ((rc = batch_reserve(ctx, B, *cp, bd))) return rc;
+    BBP_HIP_TRY(ctx, hipMemcpy(out, bd.misc + (size_t)proof * MS_COUNT, MS_COUNT * 32, hipMemcpyDeviceToHost));
+    return BBP_OK;
+}
+
+}  // namespace bbp
+
+#include "verifier.inc"

@@ -96,6 +96,19 @@ int32_t bbp_prove_batch(bbp_ctx* ctx, uint32_t B, uint32_t N, const uint8_t* in,
  * (BBP_OK / BBP_ERR_VERIFY / BBP_ERR_FORMAT). */
 int32_t bbp_verify_batch(bbp_ctx* ctx, uint32_t B, uint32_t N, const uint8_t* in, int32_t* status);
 
+/* Device-resident variants (bench.py / pipelined callers): same record layouts, every pointer a device pointer,
+ * `stream` a hipStream_t (0 = context stream), no host synchronisation, no host-side argument screening
+ * (toggle < N and canonical inputs are the caller's responsibility).  entropy_dev: B * bbp_entropy_size(N) for prove,
+ * B * 32 for verify (the verifier's TranscriptRng seed).  status_dev: B * int32. */
+int32_t bbp_prove_batch_dev(bbp_ctx* ctx, uint32_t B, uint32_t N, const void* in_dev, const void* entropy_dev, void* out_dev,
+                            void* stream);
+int32_t bbp_verify_batch_dev(bbp_ctx* ctx, uint32_t B, uint32_t N, const void* in_dev, const void* entropy_dev, void* status_dev,
+                             void* stream);
+
+/* Parity hook: the 32-scalar challenge block of proof `proof` of the LAST batch call of geometry (B, N):
+ * y z u x w y^-1 t1..t6 tb1..tb6 t_x t_x~ e~ ... (MiscSlot order in csrc/batch.h), 32 x 32 bytes. */
+int32_t bbp_debug_challenges(bbp_ctx* ctx, uint32_t B, uint32_t N, uint32_t proof, uint8_t* out32x32);
+
 /* Per-kernel device timings: with profiling on, every kernel launch is bracketed by HIP events on its launch stream.
  * bbp_last_timings synchronises, drains them as (tag, microseconds) float pairs (tags: 1 = MSM kernel, 2 = encode, ...)
  * and reports the number of floats written in *n. */

@@ -1,0 +1,156 @@
+"""GPU parity (through the C-ABI): full blind-bid prove / verify on the device against the golden fixtures (big-int oracle,
+fixed entropy) and the C oracle -- bytes identical, challenges identical, cross-acceptance both ways, tamper rejection."""
+import hashlib
+import random
+
+import pytest
+
+from oracle.ref_py import ristretto as rs
+from tests import oracle_c
+
+pytestmark = pytest.mark.gpu
+L = rs.L
+b32 = lambda x: x.to_bytes(32, "little")
+
+
+@pytest.fixture(scope="module")
+def oc(built):
+    return oracle_c.load(built.build_oracle())
+
+
+def _s7(c):
+    return b"".join(bytes.fromhex(c[k]) for k in ["d", "k", "y", "y_inv", "q", "z_img", "seed"])
+
+
+def _pub(c):
+    return b"".join(bytes.fromhex(p) for p in c["pub_list"])
+
+
+def test_witness_batch_vs_oracle(ctx, oc):
+    rnd = random.Random(11)
+    rows = [b32(1) + b32(2) + b32(3)] + [b32(rnd.getrandbits(64)) + b32(rnd.randrange(L)) + b32(rnd.randrange(L)) for _ in range(70)]
+    out = ctx.witness_batch(b"".join(rows))
+    assert out[:32].hex() == "e9c12933df0565e65eabf6436296300b1a8f9eb7355ebc1af7d0661cd8f23805"  # SURVEY.md App. B witness KAT (m)
+    for i, r in enumerate(rows):
+        assert out[192 * i:192 * i + 192] == oc.witness(r), i
+
+
+@pytest.mark.parametrize("idx", [0, 1])
+def test_prove_matches_golden_bytes(ctx, golden, idx):
+    """Fixed entropy -> byte-identical record, and the device's Fiat-Shamir challenges equal the oracle's trace."""
+    c = golden("proofs_full.json")["full"][idx]
+    rec = ctx.prove(_s7(c), _pub(c), c["toggle"], bytes.fromhex(c["entropy"]))
+    ch = ctx.debug_challenges(1, c["N"], 0)
+    for k in ["y", "z", "u", "x", "w"]:
+        assert ch[k] == c["trace"][k], k
+    assert [ch["t%d" % i] for i in range(1, 7)] == c["trace"]["t_coeffs"]
+    assert rec.hex() == c["record"]
+
+
+def test_verify_golden_and_tamper(ctx, golden):
+    for c in golden("proofs_full.json")["full"]:
+        rec = bytes.fromhex(c["record"])
+        args = (bytes.fromhex(c["q"]), bytes.fromhex(c["z_img"]), bytes.fromhex(c["seed"]), _pub(c))
+        assert ctx.verify(rec, *args) == 0
+        assert ctx.verify(rec, bytes.fromhex(c["z_img"]), *args[1:]) == 1            # wrong score
+        assert ctx.verify(rec, args[0], bytes.fromhex(c["q"]), *args[2:]) == 1       # wrong z_img
+        assert ctx.verify(rec, args[0], args[1], bytes.fromhex(c["q"]), args[3]) == 1  # wrong seed
+        pub = bytearray(args[3])
+        pub[32 * c["toggle"]] ^= 1
+        assert ctx.verify(rec, args[0], args[1], args[2], bytes(pub)) == 1           # x not in list
+        for pos in (1, 40, 1 + 32 * 8 + 3, 1 + 32 * 11 + 5, c["proof_len"] - 40, c["proof_len"] + 5, len(rec) - 1):
+            bad = bytearray(rec)
+            bad[pos] ^= 1
+            assert ctx.verify(bytes(bad), *args) in (1, 3), pos
+        assert ctx.verify(b"\x02" + rec[1:], *args) == 3                             # bad version byte
+        nc = bytearray(rec)
+        nc[1 + 32 * 8:1 + 32 * 9] = b"\xff" * 32                                     # non-canonical t_x -> FormatError
+        assert ctx.verify(bytes(nc), *args) == 3
+        zero = bytearray(rec)
+        zero[1:33] = bytes(32)                                                       # identity A_I1 -> VerificationError
+        assert ctx.verify(bytes(zero), *args) == 1
+        assert ctx.verify(rec[:-1], *args) == 3                                      # wrong length
+
+
+def _synth_batch(ctx, B, N, seed):
+    """SURVEY.md 8d recipe: SHA-512 counter stream; d = u64, k uniform, one seed per batch, x_i at toggle_i = i mod N."""
+    def stream(i, tag):
+        return hashlib.sha512(b"bbp-bench-v1" + (seed).to_bytes(8, "little") + (i).to_bytes(8, "little") + tag).digest()
+    sd = rs.sc_wide(stream(0, b"seed"))
+    dks = b"".join(stream(i, b"d")[:8] + bytes(24) + rs.sc_bytes(rs.sc_wide(stream(i, b"k"))) + rs.sc_bytes(sd) for i in range(B))
+    w = ctx.witness_batch(dks)
+    ins, ents, vins = [], [], []
+    for i in range(B):
+        m, x, y, yi, q, z = (w[192 * i + 32 * j:192 * i + 32 * j + 32] for j in range(6))
+        toggle = i % N
+        pub = [rs.sc_bytes(rs.sc_wide(stream(i, b"pub%d" % j))) for j in range(N)]
+        pub[toggle] = x
+        d, k = dks[96 * i:96 * i + 32], dks[96 * i + 32:96 * i + 64]
+        ins.append(d + k + y + yi + q + z + rs.sc_bytes(sd) + b"".join(pub) + toggle.to_bytes(8, "little"))
+        ent = b"".join(rs.sc_bytes(rs.sc_wide(stream(i, b"ent%d" % j))) for j in range(4 + N)) + stream(i, b"entseed")[:32]
+        ents.append(ent)
+        vins.append((q, z, rs.sc_bytes(sd), b"".join(pub)))
+    return ins, ents, vins
+
+
+@pytest.mark.parametrize("N,B", [(8, 6), (1, 3), (3, 4)])
+def test_batch_prove_three_way(ctx, oc, bbp, N, B):
+    """Device prover == C oracle byte for byte under injected entropy; each side's verifier accepts the other's proofs."""
+    ins, ents, vins = _synth_batch(ctx, B, N, seed=7 + N)
+    out, st = ctx.prove_batch(B, N, b"".join(ins), b"".join(ents))
+    assert st == [0] * B
+    rs_ = bbp.record_size(N)
+    cout, cst = oc.prove_many(b"".join(ins), b"".join(ents), B, N, threads=4)
+    assert cst == [0] * B
+    for i in range(B):
+        assert out[i * rs_:(i + 1) * rs_] == cout[i * rs_:(i + 1) * rs_], i
+    vin = b"".join(out[i * rs_:(i + 1) * rs_] + v[0] + v[1] + v[2] + v[3] for i, v in enumerate(vins))
+    assert oc.verify_many(vin, B, N, threads=4) == [0] * B          # oracle accepts device proofs
+    assert ctx.verify_batch(B, N, vin) == [0] * B                   # device accepts (== oracle's) proofs
+    bad = bytearray(vin)
+    stride = rs_ + 96 + 32 * N
+    bad[1 * stride + 200] ^= 0x10
+    exp = [0] * B
+    exp[1] = 1
+    assert ctx.verify_batch(B, N, bytes(bad)) == exp
+
+
+def test_prove_os_entropy_roundtrip(ctx, oc):
+    """entropy = NULL: OS randomness; two runs differ (like the reference's thread_rng) and both verify everywhere."""
+    ins, _, vins = _synth_batch(ctx, 2, 8, seed=99)
+    s7, pub = ins[0][:224], ins[0][224:224 + 256]
+    r1 = ctx.prove(s7, pub, 0)
+    r2 = ctx.prove(s7, pub, 0)
+    assert r1 != r2
+    for r in (r1, r2):
+        assert ctx.verify(r, *vins[0]) == 0
+        assert oc.verify(r, *vins[0]) == 0
+
+
+def test_argument_screening(ctx, bbp, golden):
+    c = golden("proofs_full.json")["full"][1]
+    with pytest.raises(bbp.BbpError) as e:
+        ctx.prove(_s7(c), _pub(c), 8, bytes.fromhex(c["entropy"]))       # toggle >= N
+    assert e.value.status == 4
+    with pytest.raises(bbp.BbpError) as e:
+        ctx.prove(_s7(c), b"", 0, None)                                    # N = 0 (reference panics)
+    assert e.value.status == 4
+    with pytest.raises(bbp.BbpError) as e:
+        ctx.prove(_s7(c), bytes(32 * 203), 0, bytes(bbp.entropy_size(203)))  # 2051 multipliers > 2048 generators
+    assert e.value.status == 2
+    bad = bytearray(_s7(c))
+    bad[0:32] = b"\xff" * 32
+    with pytest.raises(bbp.BbpError) as e:
+        ctx.prove(bytes(bad), _pub(c), 0, bytes.fromhex(c["entropy"]))   # non-canonical d
+    assert e.value.status == 3
+
+
+def test_max_list_length(ctx, oc, bbp):
+    """N = 202 is the largest list the 2048-generator capacity admits (1442 + 3*202 = 2048 multipliers, no padding)."""
+    ins, ents, vins = _synth_batch(ctx, 1, 202, seed=5)
+    out, st = ctx.prove_batch(1, 202, ins[0], ents[0])
+    assert st == [0]
+    assert ctx.verify(out, *vins[0]) == 0
+    assert oc.verify(out, *vins[0]) == 0
+    rc, crec = oc.prove(ins[0][:224], ins[0][224:224 + 32 * 202], 0, ents[0])
+    assert rc == 0 and crec == out
