@@ -1,20 +1,19 @@
 #!/usr/bin/env python3
 """bench.py -- blind-bid Bulletproofs hot path on MI355X (one process per GPU).
 
-    python bench.py --gpus N --steps K --warmup W [--workload msm|prove|verify] [--batch B] [--items N_ITEMS]
+    python bench.py --gpus N --steps K --warmup W [--workload prove|verify|msm] [--batch B] [--items N_ITEMS]
 
 A "step" is one pass of the hot path over one batch of B synthetic bids whose inputs are already resident in HBM.
-  workload msm   : BASELINE.json configs[1] -- per proof the three commitment MSMs A_I1/A_O1/S1
-                   (2933 + 1467 + 2933 terms at N_ITEMS = 8) over the shared generator table, compressed outputs.
-  workload prove : configs[2] -- full R1CS prove of B bids (gadgets, MSMs, polynomial sweep, IPA), records out.
-  workload verify: B full verifications.
-Each rank works on its own B proofs (independent units, no data-path collective; weak scaling); the only
-collective is the final gather of per-rank throughput (and, for prove, of proof records) to rank 0.
-Prints ONE JSON line on rank 0.  cpu_baseline (rank 0, N=1 only) times the C oracle on the host cores.
+  workload prove (default): BASELINE.json configs[2] -- full R1CS prove of B = 1024 bids (gadget witness, Merlin, commitment
+                   MSMs, polynomial sweep, 11 IPA rounds), proof records out.  `value` = proofs/s.
+  workload verify: B full verifications (one 4098-term fixed-base MSM + ~45 proof points each).
+  workload msm   : configs[1] -- per proof only the three commitment MSMs A_I1/A_O1/S1 (2933 + 1467 + 2933 terms at N = 8).
+After the timed region the default run also measures the other two workloads for a few steps and reports them as
+`also` (same JSON line), so one run carries proofs/s, verifies/s and the MSM-stage rate.
+Each rank works on its own B proofs (independent units, no data-path collective; weak scaling); the only collective is the
+final gather of proof records / flags to rank 0.  cpu_baseline (rank 0, N=1 only) times the C oracle on the host cores.
 """
 import argparse
-import ctypes
-import hashlib
 import json
 import os
 import sys
@@ -24,7 +23,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-TAG_MSM = 1
 
 
 def synth_scalars_device(torch, n_rows, n_terms, seed, device):
@@ -38,15 +36,45 @@ def synth_scalars_device(torch, n_rows, n_terms, seed, device):
     return w.to(torch.int32).contiguous()  # bit pattern of u32 LE limbs
 
 
+def timed(wl, ctx, torch, dist, world, steps, stream):
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    ctx.set_profiling(True)
+    ctx.last_timings()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wl.step(stream)
+    barrier()
+    dt = time.perf_counter() - t0
+    timings = ctx.last_timings()
+    ctx.set_profiling(False)
+    return dt, timings
+
+
+def roofline(wl, timings, steps):
+    dom = [us for tag, us in timings if tag == wl.dominant_tag]
+    avg_us = sum(dom) / max(len(dom), 1)
+    alg_per_launch = wl.alg_bytes_per_step / wl.dominant_launches_per_step
+    achieved = alg_per_launch / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": wl.measured_traffic_bytes, "kernel": wl.dominant_kernel, "avg_launch_us": avg_us, "launches": len(dom),
+            "alg_bytes_per_launch": alg_per_launch,
+            "note": "modular-integer path: the binding roofline is 32-bit integer multiply issue, not HBM (DESIGN.md section 5)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default=os.environ.get("BBP_BENCH_WORKLOAD", "auto"))
+    ap.add_argument("--workload", default=os.environ.get("BBP_BENCH_WORKLOAD", "prove"))
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--items", type=int, default=8, help="bid-list length N (SURVEY.md 8d default 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the secondary verify / msm-stage measurements")
     args = ap.parse_args()
 
     import torch
@@ -55,11 +83,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
 
     import __graft_entry__ as ge
     if rank == 0:
@@ -68,63 +96,59 @@ def main():
     if world > 1:
         dist.barrier()
     import dusk_blindbidproof_amd as bbp
-    from bench_workloads import make_workload
+    from bench_workloads import make_workload, MsmWorkload, VerifyWorkload
 
     ctx = bbp.Context(local_rank)
     wl = make_workload(args.workload, ctx, bbp, torch, device, args.batch, args.items, seed=1 + rank)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     stream = torch.cuda.current_stream().cuda_stream
     for _ in range(args.warmup):
         wl.step(stream)
     torch.cuda.synchronize()
-    wl.check()  # parity of the warmed-up output against the oracle on a small sample (not timed)
+    wl.check()  # parity of the warmed-up output against the oracle on a sample (not timed)
 
-    ctx.set_profiling(True)
-    ctx.last_timings()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        wl.step(stream)
-    barrier()
-    dt = time.perf_counter() - t0
-    timings = ctx.last_timings()
-    ctx.set_profiling(False)
-
+    dt, timings = timed(wl, ctx, torch, dist, world, args.steps, stream)
     tmax = torch.tensor([dt], device=device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        wl.gather(dist, rank, world)  # final proof/flag gather to rank 0 (RCCL), outside the timed region's units
+        wl.gather(dist, rank, world)  # the path's one collective: proof records / flags to rank 0
     dt = float(tmax.item())
+
+    also = {}
+    if args.workload == "prove" and not args.no_also:
+        for name, cls in (("verify", VerifyWorkload), ("msm_stage", MsmWorkload)):
+            kw = {"prove_wl": wl} if cls is VerifyWorkload else {}
+            w2 = cls(ctx, bbp, torch, device, args.batch, args.items, 1 + rank, **kw)
+            w2.step(stream)
+            torch.cuda.synchronize()
+            w2.check()
+            d2, t2 = timed(w2, ctx, torch, dist, world, 3, stream)
+            t2max = torch.tensor([d2], device=device, dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(t2max, op=dist.ReduceOp.MAX)
+            d2 = float(t2max.item())
+            also[name] = {"metric": w2.metric, "value": w2.units_per_step * 3 * world / d2, "unit": w2.unit, "steps": 3,
+                          "ms_per_step": d2 / 3 * 1e3, "config": w2.config, "roofline": roofline(w2, t2, 3)}
+            if rank == 0 and world == 1 and not args.no_cpu_baseline and name == "verify":
+                also[name]["cpu_baseline"] = w2.cpu_baseline()
+            del w2
 
     if rank == 0:
         units = wl.units_per_step * args.steps * world
-        value = units / dt
-        dom = [us for tag, us in timings if tag == wl.dominant_tag]
-        avg_us = sum(dom) / max(len(dom), 1)
-        alg_bytes = wl.dominant_alg_bytes_per_launch
-        achieved = alg_bytes / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
         out = {
-            "metric": wl.metric, "value": value, "unit": wl.unit, "n_gpus": world, "steps": args.steps,
+            "metric": wl.metric, "value": units / dt, "unit": wl.unit, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": wl.config,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": wl.measured_traffic_bytes,
-                         "kernel": wl.dominant_kernel, "avg_launch_us": avg_us, "launches": len(dom),
-                         "alg_bytes_per_launch": alg_bytes,
-                         "note": "integer-ALU-bound path: see DESIGN.md for the v_mad_u64_u32 roofline"},
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic", "config": wl.config,
+            "roofline": roofline(wl, timings, args.steps),
         }
         out.update(wl.extra_report(timings))
+        if also:
+            out["also"] = also
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = wl.cpu_baseline()
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

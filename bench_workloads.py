@@ -1,11 +1,12 @@
 """Synthetic workloads for bench.py (SURVEY.md 8d recipes). Inputs live in HBM before the timed region starts."""
-import ctypes
+import hashlib
 import os
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-TAG_NAMES = {1: "k_msm", 2: "k_encode", 3: "k_witness", 4: "k_rng", 5: "k_poly", 6: "k_ipa_scalars", 7: "k_commit",
-             8: "k_transcript", 9: "k_verify_scalars", 10: "k_varbase"}
+TAG_NAMES = {1: "k_msm", 2: "k_encode", 3: "k_witness", 4: "k_tr_open(rng)", 5: "k_poly/powers/flatten", 6: "k_ipa_round", 7: "k_commit",
+             8: "k_transcript", 9: "k_vscalars", 10: "k_varbase"}
+L = 2**252 + 27742317777372353535851937790883648493
 
 
 def _oracle_lib():
@@ -18,14 +19,65 @@ def _oracle_lib():
     return oracle_c.load(path)
 
 
-class MsmWorkload:
-    """BASELINE.json configs[1]: B proofs x (A_I1: 1+2n1, A_O1: 1+n1, S1: 1+2n1 terms), n1 = 1442 + 3N."""
+def _stream(seed, i, tag):
+    """SURVEY.md 8d PRNG: SHA-512 counter stream."""
+    return hashlib.sha512(b"bbp-bench-v1" + seed.to_bytes(8, "little") + i.to_bytes(8, "little") + tag).digest()
 
-    metric = "blind-bid proofs/sec (commitment-MSM stage: A_I1+A_O1+S1 per proof)"
-    unit = "proofs/s"
+
+def _wide(b):
+    return (int.from_bytes(b, "little") % L).to_bytes(32, "little")
+
+
+def synth_bids(ctx, B, N, seed):
+    """d = uniform u64, k uniform scalar, ONE seed per batch, witness on the device, x_i placed at toggle_i = i mod N."""
+    sd = _wide(_stream(seed, 0, b"seed"))
+    dks = b"".join(_stream(seed, i, b"d")[:8] + bytes(24) + _wide(_stream(seed, i, b"k")) + sd for i in range(B))
+    w = ctx.witness_batch(dks)
+    ins, ents, pubs, qz = [], [], [], []
+    for i in range(B):
+        m, x, y, yi, q, z = (w[192 * i + 32 * j:192 * i + 32 * j + 32] for j in range(6))
+        toggle = i % N
+        pub = [_wide(_stream(seed, i, b"pub%d" % j)) for j in range(N)]
+        pub[toggle] = x
+        pub = b"".join(pub)
+        ins.append(dks[96 * i:96 * i + 64] + y + yi + q + z + sd + pub + toggle.to_bytes(8, "little"))
+        ents.append(b"".join(_wide(_stream(seed, i, b"ent%d" % j)) for j in range(4 + N)) + _stream(seed, i, b"entseed")[:32])
+        pubs.append(pub)
+        qz.append(q + z + sd)
+    return ins, ents, pubs, qz
+
+
+def _to_dev(torch, device, data):
+    t = torch.frombuffer(bytearray(data), dtype=torch.uint8)
+    return t.to(device)
+
+
+def _kernel_table(timings):
+    agg = {}
+    for tag, us in timings:
+        a = agg.setdefault(TAG_NAMES.get(tag, str(tag)), [0, 0.0])
+        a[0] += 1
+        a[1] += us
+    return {k: {"launches": v[0], "total_us": round(v[1], 1)} for k, v in agg.items()}
+
+
+class _Base:
     dominant_tag = 1
     dominant_kernel = "k_msm"
     measured_traffic_bytes = None
+
+    def extra_report(self, timings):
+        return {"kernels_us": _kernel_table(timings)}
+
+    def gather(self, dist, rank, world):
+        pass
+
+
+class MsmWorkload(_Base):
+    """BASELINE.json configs[1]: B proofs x (A_I1: 1+2n1, A_O1: 1+n1, S1: 1+2n1 terms), n1 = 1442 + 3N."""
+
+    metric = "blind-bid proofs/sec (commitment-MSM stage only: A_I1+A_O1+S1 per proof)"
+    unit = "proofs/s"
 
     def __init__(self, ctx, bbp, torch, device, batch, items, seed):
         self.ctx, self.bbp, self.torch, self.B = ctx, bbp, torch, batch
@@ -39,7 +91,7 @@ class MsmWorkload:
         terms = sum(n for n, _ in self.shapes)
         # 160 B read per term (32 B scalar + 128 B extended point) + 32 B written per MSM
         self.alg_bytes_per_step = batch * (terms * 160 + 32 * len(self.shapes))
-        self.dominant_alg_bytes_per_launch = self.alg_bytes_per_step / len(self.shapes)
+        self.dominant_launches_per_step = len(self.shapes)
         self.config = {"workload": "configs[1]: batch of %d blind-bid proofs, commitment MSMs only (N=%d: %s terms)"
                        % (batch, items, "+".join(str(n) for n, _ in self.shapes)),
                        "batch_per_gpu": batch, "bid_list_len": items, "msm_window_bits": 11, "parallelism": "batch-sharded"}
@@ -50,54 +102,161 @@ class MsmWorkload:
 
     def check(self):
         lib = _oracle_lib()
-        rows = [0, self.B - 1]
         for (n, layout), s, o in zip(self.shapes, self.scal, self.out):
-            for r in rows:
+            for r in (0, self.B - 1):
                 sc = bytes(s[r].cpu().numpy().tobytes())
                 got = bytes(o[r].cpu().numpy().tobytes())
-                if lib is not None:
-                    exp = lib.msm_layout(sc, n, layout)
-                else:
-                    from oracle.ref_py import blindbid as bb, ristretto as rs
-                    pc, bp = bb.gens(2048)
-                    m = (n - 1) // 2 if layout == 0 else n - 1
-                    bases = [pc.B_blinding] + bp.G[:m] + (bp.H[:m] if layout == 0 else [])
-                    exp = rs.encode(rs.msm([int.from_bytes(sc[32 * i:32 * i + 32], "little") for i in range(n)], bases))
-                if got != exp:
+                if got != lib.msm_layout(sc, n, layout):
                     raise SystemExit("PARITY FAILURE in bench msm workload row %d" % r)
 
     def gather(self, dist, rank, world):
         t = self.out[0]
-        if rank == 0:
-            bufs = [self.torch.empty_like(t) for _ in range(world)]
-            dist.gather(t, bufs, dst=0)
-        else:
-            dist.gather(t, None, dst=0)
-
-    def extra_report(self, timings):
-        agg = {}
-        for tag, us in timings:
-            a = agg.setdefault(TAG_NAMES.get(tag, str(tag)), [0, 0.0])
-            a[0] += 1
-            a[1] += us
-        return {"kernels_us": {k: {"launches": v[0], "total_us": round(v[1], 1)} for k, v in agg.items()}}
+        dist.gather(t, [self.torch.empty_like(t) for _ in range(world)] if rank == 0 else None, dst=0)
 
     def cpu_baseline(self):
         lib = _oracle_lib()
-        if lib is None:
-            return None
         threads = os.cpu_count() or 1
-        sample = max(threads, 8)
+        sample = max(2 * threads, 8)
         rows = [bytes(self.scal[i][r % self.B].cpu().numpy().tobytes()) for r in range(sample) for i in range(3)]
         t0 = time.perf_counter()
         lib.msm_layout_many(rows, [self.shapes[i % 3][0] for i in range(len(rows))],
                             [self.shapes[i % 3][1] for i in range(len(rows))], threads)
         dt = time.perf_counter() - t0
         return {"value": sample / dt, "unit": self.unit, "cores": threads, "kind": "port",
-                "sample": "%d proofs' A_I1+A_O1+S1 MSMs (Pippenger, C oracle, %d threads) in %.1f s" % (sample, threads, dt)}
+                "sample": "%d proofs' A_I1+A_O1+S1 MSMs (vartime Pippenger, C oracle, %d threads) in %.1f s" % (sample, threads, dt)}
+
+
+class ProveWorkload(_Base):
+    """BASELINE.json configs[2]: batch of B full R1CS proves (gadgets + MSMs + polynomial sweep + IPA) on one GPU."""
+
+    metric = "blind-bid proofs/sec"
+    unit = "proofs/s"
+
+    def __init__(self, ctx, bbp, torch, device, batch, items, seed):
+        self.ctx, self.bbp, self.torch, self.B, self.N, self.device = ctx, bbp, torch, batch, items, device
+        self.ins, self.ents, self.pubs, self.qz = synth_bids(ctx, batch, items, seed)
+        self.in_dev = _to_dev(torch, device, b"".join(self.ins))
+        self.ent_dev = _to_dev(torch, device, b"".join(self.ents))
+        self.rec = bbp.record_size(items)
+        self.out_dev = torch.zeros(batch * self.rec, dtype=torch.uint8, device=device)
+        self.units_per_step = batch
+        n1 = 1442 + 3 * items
+        commit_terms = (1 + 2 * n1) * 2 + (1 + n1)
+        ipa_terms = 22 * 2049
+        # the engine's k_msm launches per prove step: 3 commitment launches + 11 IPA launches (2 MSMs per proof each)
+        self.alg_bytes_per_step = batch * ((commit_terms + ipa_terms) * 160 + 32 * (3 + 22))
+        self.dominant_launches_per_step = 3 + 11
+        self.config = {"workload": "configs[2]: batch of %d full blind-bid R1CS proves (N=%d, 1466 multipliers, 11 IPA rounds)" % (batch, items),
+                       "batch_per_gpu": batch, "bid_list_len": items, "msm_window_bits": 11, "parallelism": "batch-sharded",
+                       "msm_terms_per_proof": commit_terms + ipa_terms}
+
+    def step(self, stream):
+        self.ctx.prove_batch_dev(self.B, self.N, self.in_dev.data_ptr(), self.ent_dev.data_ptr(), self.out_dev.data_ptr(), stream)
+
+    def records(self):
+        return bytes(self.out_dev.cpu().numpy().tobytes())
+
+    def check(self):
+        lib = _oracle_lib()
+        out = self.records()
+        for r in (0, self.B - 1):
+            got = out[r * self.rec:(r + 1) * self.rec]
+            ins = self.ins[r]
+            rc, exp = lib.prove(ins[:224], ins[224:224 + 32 * self.N], int.from_bytes(ins[-8:], "little"), self.ents[r])
+            if rc != 0 or got != exp:
+                raise SystemExit("PARITY FAILURE in bench prove workload row %d" % r)
+            if lib.verify(got, self.qz[r][:32], self.qz[r][32:64], self.qz[r][64:96], self.pubs[r]) != 0:
+                raise SystemExit("oracle verifier rejected device proof %d" % r)
+
+    def gather(self, dist, rank, world):
+        """The one collective of the path: fixed-stride proof records to rank 0 (RCCL over xGMI)."""
+        t = self.out_dev
+        dist.gather(t, [self.torch.empty_like(t) for _ in range(world)] if rank == 0 else None, dst=0)
+
+    def cpu_baseline(self):
+        lib = _oracle_lib()
+        threads = os.cpu_count() or 1
+        sample = 2 * threads
+        ins = b"".join(self.ins[i % self.B] for i in range(sample))
+        ents = b"".join(self.ents[i % self.B] for i in range(sample))
+        t0 = time.perf_counter()
+        _, st = lib.prove_many(ins, ents, sample, self.N, threads)
+        dt = time.perf_counter() - t0
+        assert st == [0] * sample
+        return {"value": sample / dt, "unit": self.unit, "cores": threads, "kind": "port",
+                "sample": "%d full proves (C oracle: the reference's algorithm incl. generator folding, serial 64-bit limbs, one proof per "
+                          "thread, %d threads) in %.1f s; reference's own published figure: 0.261 s per prove+verify on an i7-8559U "
+                          "(docs/benchmarks.png)" % (sample, threads, dt)}
+
+
+class VerifyWorkload(_Base):
+    """B full verifications of device-made proofs (1 % corrupted at known indices)."""
+
+    metric = "blind-bid verifies/sec"
+    unit = "verifies/s"
+
+    def __init__(self, ctx, bbp, torch, device, batch, items, seed, prove_wl=None):
+        self.ctx, self.bbp, self.torch, self.B, self.N = ctx, bbp, torch, batch, items
+        pw = prove_wl or ProveWorkload(ctx, bbp, torch, device, batch, items, seed)
+        pw.step(0)
+        torch.cuda.synchronize()
+        recs = pw.records()
+        rec = pw.rec
+        self.stride = rec + 96 + 32 * items
+        rows = [bytearray(recs[i * rec:(i + 1) * rec] + pw.qz[i] + pw.pubs[i]) for i in range(batch)]
+        self.bad = sorted(set((i * 97 + 13) % batch for i in range(max(batch // 100, 1))))
+        for i in self.bad:
+            rows[i][100 + (i % 900)] ^= 0x20
+        self.rows = rows
+        self.in_dev = _to_dev(torch, device, b"".join(bytes(r) for r in rows))
+        self.ent_dev = _to_dev(torch, device, hashlib.shake_256(b"verifier-entropy%d" % seed).digest(32 * batch))
+        self.status = torch.full((batch,), -1, dtype=torch.int32, device=device)
+        self.units_per_step = batch
+        self.alg_bytes_per_step = batch * (4098 * 160 + 32)   # the fixed-base mega-check MSM launch
+        self.dominant_launches_per_step = 1
+        self.config = {"workload": "batch of %d full blind-bid verifications (N=%d), %d corrupted" % (batch, items, len(self.bad)),
+                       "batch_per_gpu": batch, "bid_list_len": items, "parallelism": "batch-sharded"}
+
+    def step(self, stream):
+        self.ctx.verify_batch_dev(self.B, self.N, self.in_dev.data_ptr(), self.ent_dev.data_ptr(), self.status.data_ptr(), stream)
+
+    def check(self):
+        st = self.status.cpu().tolist()
+        exp = [0] * self.B
+        for i in self.bad:
+            exp[i] = None
+        for i, (a, b) in enumerate(zip(st, exp)):
+            if (b == 0 and a != 0) or (b is None and a not in (1, 3)):
+                raise SystemExit("verify workload: wrong status %d at %d" % (a, i))
+        lib = _oracle_lib()
+        for i in (0, self.bad[0]):
+            r = bytes(self.rows[i])
+            rec = self.bbp.record_size(self.N)
+            c = lib.verify(r[:rec], r[rec:rec + 32], r[rec + 32:rec + 64], r[rec + 64:rec + 96], r[rec + 96:])
+            if (c == 0) != (st[i] == 0):
+                raise SystemExit("verify workload: oracle disagrees at %d" % i)
+
+    def gather(self, dist, rank, world):
+        t = self.status
+        dist.gather(t, [self.torch.empty_like(t) for _ in range(world)] if rank == 0 else None, dst=0)
+
+    def cpu_baseline(self):
+        lib = _oracle_lib()
+        threads = os.cpu_count() or 1
+        sample = 16 * threads
+        vin = b"".join(bytes(self.rows[i % self.B]) for i in range(sample))
+        t0 = time.perf_counter()
+        lib.verify_many(vin, sample, self.N, threads)
+        dt = time.perf_counter() - t0
+        return {"value": sample / dt, "unit": self.unit, "cores": threads, "kind": "port",
+                "sample": "%d verifications (C oracle, %d threads) in %.1f s" % (sample, threads, dt)}
 
 
 def make_workload(name, ctx, bbp, torch, device, batch, items, seed):
-    if name in ("auto", "msm"):
+    if name in ("auto", "prove"):
+        return ProveWorkload(ctx, bbp, torch, device, batch, items, seed)
+    if name == "msm":
         return MsmWorkload(ctx, bbp, torch, device, batch, items, seed)
+    if name == "verify":
+        return VerifyWorkload(ctx, bbp, torch, device, batch, items, seed)
     raise SystemExit("unknown workload %r" % name)
