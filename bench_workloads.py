@@ -19,6 +19,18 @@ def _oracle_lib():
     return oracle_c.load(path)
 
 
+def host_threads():
+    """CPU threads this process may really use: cgroup quota if set, else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("BBP_CPU_THREADS", "64"))))
+
+
 def _stream(seed, i, tag):
     """SURVEY.md 8d PRNG: SHA-512 counter stream."""
     return hashlib.sha512(b"bbp-bench-v1" + seed.to_bytes(8, "little") + i.to_bytes(8, "little") + tag).digest()
@@ -115,7 +127,7 @@ class MsmWorkload(_Base):
 
     def cpu_baseline(self):
         lib = _oracle_lib()
-        threads = os.cpu_count() or 1
+        threads = host_threads()
         sample = max(2 * threads, 8)
         rows = [bytes(self.scal[i][r % self.B].cpu().numpy().tobytes()) for r in range(sample) for i in range(3)]
         t0 = time.perf_counter()
@@ -170,12 +182,12 @@ class ProveWorkload(_Base):
 
     def gather(self, dist, rank, world):
         """The one collective of the path: fixed-stride proof records to rank 0 (RCCL over xGMI)."""
-        t = self.out_dev
-        dist.gather(t, [self.torch.empty_like(t) for _ in range(world)] if rank == 0 else None, dst=0)
+        from dusk_blindbidproof_amd import sharding
+        return sharding.gather_records(dist, self.out_dev, self.rec, self.B * world, rank, world)
 
     def cpu_baseline(self):
         lib = _oracle_lib()
-        threads = os.cpu_count() or 1
+        threads = host_threads()
         sample = 2 * threads
         ins = b"".join(self.ins[i % self.B] for i in range(sample))
         ents = b"".join(self.ents[i % self.B] for i in range(sample))
@@ -237,12 +249,12 @@ class VerifyWorkload(_Base):
                 raise SystemExit("verify workload: oracle disagrees at %d" % i)
 
     def gather(self, dist, rank, world):
-        t = self.status
-        dist.gather(t, [self.torch.empty_like(t) for _ in range(world)] if rank == 0 else None, dst=0)
+        from dusk_blindbidproof_amd import sharding
+        return sharding.gather_records(dist, self.status.view(self.torch.uint8), 4, self.B * world, rank, world)
 
     def cpu_baseline(self):
         lib = _oracle_lib()
-        threads = os.cpu_count() or 1
+        threads = host_threads()
         sample = 16 * threads
         vin = b"".join(bytes(self.rows[i % self.B]) for i in range(sample))
         t0 = time.perf_counter()

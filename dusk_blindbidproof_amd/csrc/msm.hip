@@ -70,7 +70,8 @@ __device__ __forceinline__ void for_each_digit(const u32 (&s)[8], F&& f) {
 
 __global__ __launch_bounds__(MSM_T) void k_msm(const u32* __restrict__ scalars, const u32* __restrict__ base_idx_sets, u32 n,
                                                 u32 n_idx_sets, const ge_niels* __restrict__ wtable,
-                                                u32* __restrict__ sorted_all, ge* __restrict__ out) {
+                                                u32* __restrict__ sorted_all, ge* __restrict__ bsum_all, ge* __restrict__ psum_all,
+                                                ge* __restrict__ out) {
     __shared__ u32 cnt[MSM_K + 1];
     __shared__ u32 cursor[MSM_K + 1];
     __shared__ u32 part[MSM_T];
@@ -132,21 +133,58 @@ __global__ __launch_bounds__(MSM_T) void k_msm(const u32* __restrict__ scalars, 
     __threadfence_block();
     __syncthreads();
 
-    // D. bucket sums + running-sum fold over this lane's 8 buckets (high to low)
+    // D1. balanced bucket accumulation: the sorted entry array is cut into 128 EQUAL chunks, one per lane, whatever the
+    //     bucket sizes are (a scalar repeated hundreds of times -- the padding rows of the first IPA round -- would
+    //     otherwise serialise one lane).  A chunk that starts inside a bucket parks that leading partial sum in psum[lane];
+    //     every other bucket (or bucket head) it meets goes to bsum[bucket].  cursor[k] = end offset of bucket k now.
+    const u32 E = cursor[MSM_K];
+    if (tid == 0) cursor[0] = 0;
+    ge* bsum = bsum_all + msm * (size_t)MSM_K;           // [K] bucket k at index k-1
+    ge* psum = psum_all + msm * (size_t)MSM_T;           // [T]
+    const u32 c0 = (u32)(((u64)tid * E) / MSM_T), c1 = (u32)(((u64)(tid + 1) * E) / MSM_T);
+    __syncthreads();
+    if (c0 < c1) {
+        // bucket containing entry c0: smallest k with cursor[k] > c0
+        u32 lo = 1, hi = MSM_K;
+        while (lo < hi) {
+            u32 mid = (lo + hi) >> 1;
+            if (cursor[mid] > c0) hi = mid; else lo = mid + 1;
+        }
+        u32 k = lo, kend = cursor[k];
+        ge* dest = (cursor[k - 1] < c0) ? &psum[tid] : &bsum[k - 1];
+        ge acc = ge_identity();
+        ge_niels nxt = load_niels(wtable, sorted[c0]);
+        for (u32 e = c0; e < c1; e++) {
+            if (e == kend) {  // crossed into the next non-empty bucket
+                *dest = acc;
+                acc = ge_identity();
+                do { k++; kend = cursor[k]; } while (kend == e);
+                dest = &bsum[k - 1];
+            }
+            ge_niels cur = nxt;
+            if (e + 1 < c1) nxt = load_niels(wtable, sorted[e + 1]);
+            acc = ge_madd(acc, cur);
+        }
+        *dest = acc;
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // D2. running-sum fold over this lane's 8 buckets (high to low), all lanes in lockstep
     ge running = ge_identity(), total = ge_identity();
     for (int r = MSM_G; r >= 1; r--) {
-        const int k = tid * MSM_G + r;
-        const u32 end = cursor[k];
-        const u32 beg = end - cnt[k];
-        if (beg != end) {
-            ge acc = ge_identity();
-            ge_niels nxt = load_niels(wtable, sorted[beg]);
-            for (u32 e = beg; e < end; e++) {
-                ge_niels cur = nxt;
-                if (e + 1 < end) nxt = load_niels(wtable, sorted[e + 1]);
-                acc = ge_madd(acc, cur);
+        const u32 k = tid * MSM_G + r;
+        const u32 kend = cursor[k], kbeg = cursor[k - 1];
+        if (kbeg != kend) {
+            running = ge_add(running, bsum[k - 1]);
+            // chunks that START strictly inside this bucket carry a partial sum for it
+            u32 t = (u32)(((u64)kbeg * MSM_T) / E);
+            for (; t < MSM_T; t++) {
+                const u32 ct = (u32)(((u64)t * E) / MSM_T);
+                if (ct >= kend) break;
+                const u32 ct1 = (u32)(((u64)(t + 1) * E) / MSM_T);
+                if (ct > kbeg && ct1 > ct) running = ge_add(running, psum[t]);
             }
-            running = ge_add(running, acc);
         }
         total = ge_add(total, running);
     }
@@ -195,7 +233,11 @@ __global__ __launch_bounds__(64) void k_encode(const ge* __restrict__ pts, u32 n
     o[1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
 
-size_t msm_scratch_bytes(uint32_t n_msm, uint32_t n_terms) { return (size_t)n_msm * n_terms * MSM_W * sizeof(u32); }
+// per MSM: sorted entries (n * W u32), bucket sums (K points), chunk-leading partial sums (T points)
+static size_t msm_sorted_bytes(uint32_t n_msm, uint32_t n_terms) { return (((size_t)n_msm * n_terms * MSM_W * sizeof(u32)) + 255) / 256 * 256; }
+size_t msm_scratch_bytes(uint32_t n_msm, uint32_t n_terms) {
+    return msm_sorted_bytes(n_msm, n_terms) + (size_t)n_msm * (MSM_K + MSM_T) * sizeof(ge);
+}
 
 int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* scalars_dev, const u32* base_idx_dev,
                    ge* out_points_dev, hipStream_t stream, uint32_t n_idx_sets) {
@@ -206,9 +248,10 @@ int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* sc
     }
     int32_t rc = dev_reserve(ctx, ctx->sorted, msm_scratch_bytes(n_msm, n_terms));
     if (rc) return rc;
+    ge* bsum = reinterpret_cast<ge*>(static_cast<u8*>(ctx->sorted.p) + msm_sorted_bytes(n_msm, n_terms));
     ScopedEvent ev(ctx, TAG_MSM, stream);
     hipLaunchKernelGGL(k_msm, dim3(n_msm), dim3(MSM_T), 0, stream, scalars_dev, base_idx_dev, n_terms, n_idx_sets, ctx->wtable,
-                       (u32*)ctx->sorted.p, out_points_dev);
+                       (u32*)ctx->sorted.p, bsum, bsum + (size_t)n_msm * MSM_K, out_points_dev);
     BBP_HIP_TRY(ctx, hipGetLastError());
     return BBP_OK;
 }
