@@ -40,7 +40,7 @@ struct bbp_ctx {
     uint8_t gens_enc_host_valid = 0;
     std::vector<uint8_t> mimc_host;    // 90 * 32
     // grow-only scratch
-    bbp::DevBuf scal, idx, sorted, pts, enc, misc, batch, io_in, io_out, io_ent;
+    bbp::DevBuf scal, idx, sorted, pts, enc, misc, batch, io_in, io_out, io_ent, raw;
     std::map<uint32_t, void*> circuits;  // N -> CircuitDev* (compiled blind-bid circuit tables on the device)
     std::vector<float> timings;
     // optional per-kernel HIP-event timing (bbp_set_profiling): (tag, start, stop) on the launch stream

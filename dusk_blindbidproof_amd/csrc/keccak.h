@@ -12,7 +12,8 @@ namespace bbp {
 
 BBP_HD u64 rotl64(u64 x, int n) { return (x << n) | (x >> (64 - n)); }
 
-BBP_HD_NOINLINE void keccak_f1600(u64* s) {
+// forceinline body: with `s` a local array indexed statically the 25 lanes live in registers across calls
+BBP_HD void keccak_f1600_body(u64* s) {
     const u64 RC[24] = {0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808Aull, 0x8000000080008000ull,
                         0x000000000000808Bull, 0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull,
                         0x000000000000008Aull, 0x0000000000000088ull, 0x0000000080008009ull, 0x000000008000000Aull,
@@ -59,6 +60,8 @@ BBP_HD_NOINLINE void keccak_f1600(u64* s) {
     s[15] = a15; s[16] = a16; s[17] = a17; s[18] = a18; s[19] = a19;
     s[20] = a20; s[21] = a21; s[22] = a22; s[23] = a23; s[24] = a24;
 }
+
+BBP_HD_NOINLINE void keccak_f1600(u64* s) { keccak_f1600_body(s); }
 
 // ---- STROBE-128 (rate 166) -------------------------------------------------------------------------
 struct merlin_transcript {
@@ -199,6 +202,37 @@ BBP_HD void merlin_rng_fill(merlin_transcript& t, uint8_t* out, u32 n) {
     le32(len4, n);
     strobe_meta_ad(t, len4, 4, false);
     strobe_prf(t, out, n, false);
+}
+
+// `count` consecutive TranscriptRng::fill_bytes(64) calls (one per Scalar::random) in steady state.
+// After any 64-byte fill the sponge sits at pos = 64, pos_begin = 0, and the next fill is always the same byte script:
+//   meta_ad(u32_le(64))  -> absorb [0x00, M|A = 0x12] at 64,65 and [0x40,0,0,0] at 66..69
+//   prf begin            -> absorb [65, I|A|C = 0x07] at 70,71 ; run_f: st[72] ^= 71, st[73] ^= 0x04, st[167] ^= 0x80
+//   squeeze 64           -> output bytes 0..63, zero them, pos = 64
+// so each draw is three constant lane XORs, one Keccak-f[1600] and a copy of lanes 0..7 -- no byte loops, and the 25
+// lanes stay in registers for the whole run.  Returns false (and does nothing) if the sponge is not in that state.
+BBP_HD bool merlin_rng_fill64_bulk(merlin_transcript& t, u32 count, u32* out_words /* count * 16 */) {
+    if (t.pos != 64 || t.pos_begin != 0) return false;
+    u64 a[25];
+#pragma unroll
+    for (int i = 0; i < 25; i++) a[i] = t.st[i];
+    for (u32 c = 0; c < count; c++) {
+        a[8] ^= 0x0741000000401200ull;
+        a[9] ^= 0x0000000000000447ull;
+        a[20] ^= 0x8000000000000000ull;
+        keccak_f1600_body(a);
+        u32* o = out_words + (size_t)c * 16;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            o[2 * i] = (u32)a[i];
+            o[2 * i + 1] = (u32)(a[i] >> 32);
+            a[i] = 0;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 25; i++) t.st[i] = a[i];
+    t.cur_flags = BBP_FLAG_I | BBP_FLAG_A | BBP_FLAG_C;
+    return true;
 }
 
 }  // namespace bbp

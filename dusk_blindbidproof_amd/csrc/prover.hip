@@ -207,8 +207,8 @@ __global__ void k_encode_strided(u32 count, u32 per_proof, const ge* __restrict_
 __device__ __forceinline__ u32 enc_stride_words(u32 m) { return (m + 8 + 22) * 8; }
 
 __global__ void k_tr_open(u32 B, u32 m, u32 n1, merlin_transcript prefix, const u32* __restrict__ enc, const u8* __restrict__ entropy,
-                          sc* __restrict__ vb_all, sc* __restrict__ ai1, sc* __restrict__ ao1, sc* __restrict__ s1,
-                          merlin_transcript* __restrict__ tr_out, merlin_transcript* __restrict__ rng_out) {
+                          sc* __restrict__ vb_all, u32* __restrict__ raw, merlin_transcript* __restrict__ tr_out,
+                          merlin_transcript* __restrict__ rng_out) {
     u32 p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= B) return;
     merlin_transcript t = prefix;  // Transcript::new(b"BlindBidProofGadget") + r1cs_domain_sep (A.4)
@@ -227,15 +227,31 @@ __global__ void k_tr_open(u32 B, u32 m, u32 n1, merlin_transcript prefix, const 
     uint8_t seed[32];
     for (int i = 0; i < 32; i++) seed[i] = ent[i];
     merlin_rng_finalize(r, seed);
-    sc* a = ai1 + (size_t)p * (1 + 2 * n1);
-    sc* o = ao1 + (size_t)p * (1 + n1);
-    sc* s = s1 + (size_t)p * (1 + 2 * n1);
-    st_sc(&a[0], rng_scalar(r));  // i_blinding1
-    st_sc(&o[0], rng_scalar(r));  // o_blinding1
-    st_sc(&s[0], rng_scalar(r));  // s_blinding1
-    for (u32 i = 0; i < 2 * n1; i++) st_sc(&s[1 + i], rng_scalar(r));  // s_L1 then s_R1
+    // draws, in order: i_blinding1, o_blinding1, s_blinding1, s_L1[n1], s_R1[n1] (A.5 step 3).  Raw 64-byte outputs go
+    // to `raw`; the wide reductions mod l run afterwards in k_reduce_draws, off this strictly sequential chain.
+    u32* rw = raw + (size_t)p * (3 + 2 * (size_t)n1) * 16;
+    {
+        uint8_t b[64];
+        merlin_rng_fill(r, b, 64);  // first draw leaves the sponge in the steady state the bulk path needs
+        bytes_to_words(rw, b, 16);
+    }
+    merlin_rng_fill64_bulk(r, 2 + 2 * n1, rw + 16);
     tr_out[p] = t;
     rng_out[p] = r;
+}
+
+// draw j of proof p -> its scalar slot: 0 -> ai1[0], 1 -> ao1[0], 2 -> s1[0], j >= 3 -> s1[1 + (j - 3)]
+__global__ void k_reduce_draws(u32 B, u32 n1, const u32* __restrict__ raw, sc* __restrict__ ai1, sc* __restrict__ ao1, sc* __restrict__ s1) {
+    const u32 per = 3 + 2 * n1;
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * per) return;
+    u32 p = t / per, j = t % per;
+    const uint4* q = reinterpret_cast<const uint4*>(raw + (size_t)t * 16);
+    uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+    const u32 w[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+    sc v = sc_from_wide(w);
+    sc* dst = j == 0 ? &ai1[(size_t)p * (1 + 2 * n1)] : j == 1 ? &ao1[(size_t)p * (1 + n1)] : &s1[(size_t)p * (1 + 2 * n1) + (j - 2)];
+    st_sc(dst, v);
 }
 
 // blindings from the entropy block: (4+N) 32-byte values, reduced
@@ -729,7 +745,10 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
     LAUNCH(ctx, TAG_TRANSCRIPT, k_load_blindings, cdiv(B * m, 64), 64, s, B, m, ent_dev, bd.vb);
     if ((rc = commit_launch(ctx, B * m, bd.v, bd.vb, m, m, m, bd.pts, m + 8, s))) return rc;
     LAUNCH(ctx, TAG_ENCODE, k_encode_strided, cdiv(B * m, 64), 64, s, B * m, m, bd.pts, m + 8, bd.enc, encw, 0u);
-    LAUNCH(ctx, TAG_RNG, k_tr_open, cdiv(B, 64), 64, s, B, m, n1, prefix, bd.enc, ent_dev, bd.vb, bd.ai1, bd.ao1, bd.s1, bd.tr, bd.rng);
+    const size_t n_draws = 3 + 2 * (size_t)n1;
+    if ((rc = dev_reserve(ctx, ctx->raw, (size_t)B * n_draws * 64))) return rc;
+    LAUNCH(ctx, TAG_RNG, k_tr_open, cdiv(B, 64), 64, s, B, m, n1, prefix, bd.enc, ent_dev, bd.vb, (u32*)ctx->raw.p, bd.tr, bd.rng);
+    LAUNCH(ctx, TAG_RNG, k_reduce_draws, cdiv((u32)(B * n_draws), 128), 128, s, B, n1, (const u32*)ctx->raw.p, bd.ai1, bd.ao1, bd.s1);
     // A_I1, A_O1, S1 -> pts[m + 0..2] (strided output: launch per commitment with an output view)
     if ((rc = dev_reserve(ctx, ctx->pts, sizeof(ge) * (size_t)B * 3))) return rc;
     ge* tmp = static_cast<ge*>(ctx->pts.p);

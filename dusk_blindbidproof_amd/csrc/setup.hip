@@ -129,7 +129,7 @@ extern "C" void bbp_free(bbp_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    void* ptrs[] = {ctx->gens, ctx->wtable, ctx->comb, ctx->mimc_c, ctx->scal.p, ctx->idx.p, ctx->sorted.p, ctx->pts.p, ctx->enc.p, ctx->misc.p};
+    void* ptrs[] = {ctx->gens, ctx->wtable, ctx->comb, ctx->mimc_c, ctx->scal.p, ctx->idx.p, ctx->sorted.p, ctx->pts.p, ctx->enc.p, ctx->misc.p, ctx->batch.p, ctx->io_in.p, ctx->io_out.p, ctx->io_ent.p, ctx->raw.p};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

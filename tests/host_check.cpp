@@ -122,6 +122,24 @@ void hc_merlin_kat(const uint8_t* label, int label_len, const uint8_t* l1, int l
     merlin_challenge(t, l2, l2_len, out, n);
 }
 
+// bulk 64-byte draws vs the generic byte-wise path: out_generic / out_bulk = (1 + count + 1) * 64 bytes each
+int hc_merlin_rng_bulk(const uint8_t* w, int w_len, const uint8_t* ent32, int count, uint8_t* out_generic, uint8_t* out_bulk) {
+    merlin_transcript t;
+    merlin_init(t, (const uint8_t*)"BlindBidProofGadget", 19);
+    merlin_transcript a = t;
+    merlin_rng_rekey(a, (const uint8_t*)"v_blinding", 10, w, w_len);
+    merlin_rng_finalize(a, ent32);
+    merlin_transcript b = a;
+    for (int i = 0; i < count + 2; i++) merlin_rng_fill(a, out_generic + 64 * i, 64);
+    merlin_rng_fill(b, out_bulk, 64);
+    u32* words = new u32[16 * count];
+    bool ok = merlin_rng_fill64_bulk(b, count, words);
+    memcpy(out_bulk + 64, words, 64 * (size_t)count);
+    delete[] words;
+    merlin_rng_fill(b, out_bulk + 64 * (count + 1), 64);
+    return ok ? 1 : 0;
+}
+
 // TranscriptRng: Transcript(label); rng = build_rng().rekey(wl, w).finalize(ent32); fill n bytes twice
 void hc_merlin_rng(const uint8_t* label, int label_len, const uint8_t* wl, int wl_len, const uint8_t* w, int w_len,
                    const uint8_t* ent32, uint8_t* out, int n) {

@@ -124,6 +124,19 @@ def test_point_ops_and_codec(lib):
         assert out.raw == rs.encode(rs.pt_mul(s, pts[3 + i]))
 
 
+def test_rng_bulk_draws_equal_generic_path(lib):
+    """The register-resident steady-state TranscriptRng draw (keccak.h merlin_rng_fill64_bulk) == byte-wise STROBE."""
+    for count, wlen in [(1, 32), (7, 32), (50, 0), (300, 100)]:
+        n = 64 * (count + 2)
+        a, b = ctypes.create_string_buffer(n), ctypes.create_string_buffer(n)
+        w = hashlib.shake_256(b"w%d" % count).digest(wlen) if wlen else b""
+        assert lib.hc_merlin_rng_bulk(w, wlen, b"\x21" * 32, count, a, b) == 1
+        assert a.raw == b.raw
+        t = merlin.Transcript(b"BlindBidProofGadget")
+        r = t.build_rng([(b"v_blinding", w)], b"\x21" * 32)
+        assert b"".join(r.fill_bytes(64) for _ in range(count + 2)) == a.raw
+
+
 def test_keccak_and_merlin(lib):
     st = bytearray(hashlib.shake_256(b"st").digest(200))
     st2 = bytearray(st)
