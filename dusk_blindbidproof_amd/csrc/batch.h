@@ -70,7 +70,7 @@ __device__ __forceinline__ void st_sc(sc* p, const sc& s) {
 
 // prover.hip / verifier.hip
 int32_t circuit_get(bbp_ctx* ctx, uint32_t n_items, const CircuitDev** out);
-int32_t batch_reserve(bbp_ctx* ctx, uint32_t B, const CircuitDev& c, BatchDev& bd);
+int32_t batch_reserve(bbp_ctx* ctx, uint32_t B, const CircuitDev& c, BatchDev& bd, int parity);
 int32_t commit_launch(bbp_ctx* ctx, u32 count, const sc* values, const sc* blindings, u32 stride_v, u32 stride_b, u32 per_proof,
                       ge* out, u32 out_stride, hipStream_t s);
 

@@ -31,6 +31,11 @@ struct DevBuf {
 struct bbp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;            // opening stage of the prover pipeline (prover.hip)
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_open[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    bool ev_done_valid[2] = {false, false}, ev_open_valid[2] = {false, false};
+    uint32_t seq = 0;
+    int last_par = 0;
     std::string err;
     // resident tables
     bbp::ge* gens = nullptr;           // [BBP_NUM_BASES] extended points: B_blinding, G[2048], H[2048], B
@@ -40,7 +45,7 @@ struct bbp_ctx {
     uint8_t gens_enc_host_valid = 0;
     std::vector<uint8_t> mimc_host;    // 90 * 32
     // grow-only scratch
-    bbp::DevBuf scal, idx, sorted, pts, enc, misc, batch, io_in, io_out, io_ent, raw;
+    bbp::DevBuf scal, idx, sorted, pts, enc, misc, batch, batch1, io_in, io_out, io_ent, raw;
     std::map<uint32_t, void*> circuits;  // N -> CircuitDev* (compiled blind-bid circuit tables on the device)
     std::vector<float> timings;
     // optional per-kernel HIP-event timing (bbp_set_profiling): (tag, start, stop) on the launch stream

@@ -676,8 +676,9 @@ int32_t circuit_get(bbp_ctx* ctx, uint32_t n_items, const CircuitDev** out) {
     return BBP_OK;
 }
 
-int32_t batch_reserve(bbp_ctx* ctx, uint32_t B, const CircuitDev& c, BatchDev& bd) {
+int32_t batch_reserve(bbp_ctx* ctx, uint32_t B, const CircuitDev& c, BatchDev& bd, int parity) {
     const size_t n1 = c.n_mul, m = c.m;
+    DevBuf& buf = parity ? ctx->batch1 : ctx->batch;
     size_t off = 0;
     auto take = [&](size_t bytes_per_proof) {
         size_t o = off;
@@ -692,9 +693,9 @@ int32_t batch_reserve(bbp_ctx* ctx, uint32_t B, const CircuitDev& c, BatchDev& b
            o_r1 = take(n1 * S), o_r3 = take(n1 * S), o_a = take(2048 * S), o_b = take(2048 * S), o_g = take(2048 * S), o_h = take(2048 * S),
            o_lr = take(2 * 2049 * S), o_pts = take((m + 8) * sizeof(ge)), o_lrpts = take(2 * sizeof(ge)),
            o_enc = take((m + 8 + 22) * 32), o_ent = take(32 * m + 32);
-    int32_t rc = dev_reserve(ctx, ctx->batch, off);
+    int32_t rc = dev_reserve(ctx, buf, off);
     if (rc) return rc;
-    u8* base = static_cast<u8*>(ctx->batch.p);
+    u8* base = static_cast<u8*>(buf.p);
     bd.B = B;
     bd.n_items = c.n_items;
     bd.m = c.m;
@@ -734,21 +735,36 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
     int32_t rc = circuit_get(ctx, N, &cp);
     if (rc) return rc;
     const CircuitDev& c = *cp;
+    // Two-stage software pipeline across consecutive calls.  The OPENING stage (witness, V commitments, transcript open and
+    // the 2935 strictly sequential TranscriptRng draws) is latency-bound -- one lane per proof, 16 wavefronts for 1024 proofs
+    // -- so it runs on the context's side stream into the batch buffer of this call's parity, while the caller's stream is
+    // still busy with the MSM-heavy stage of the PREVIOUS call (other parity).  Events order: inputs (caller stream) ->
+    // opening (side) -> heavy stage (caller stream); a buffer is reused only after its previous heavy stage has finished.
+    const int par = (int)(ctx->seq++ & 1u);
     BatchDev bd;
-    if ((rc = batch_reserve(ctx, B, c, bd))) return rc;
+    if ((rc = batch_reserve(ctx, B, c, bd, par))) return rc;
     const u32 m = c.m, n1 = c.n_mul, encw = (m + 8 + 22) * 8;
     const merlin_transcript prefix = prover_prefix();
-
-    LAUNCH(ctx, TAG_WITNESS, k_fill_mimc, cdiv(B * BBP_MIMC_ROUNDS, 64), 64, s, B, c.n_cst, ctx->mimc_c, bd.cst);
-    LAUNCH(ctx, TAG_WITNESS, k_witness, cdiv(B, 64), 64, s, B, N, n1, c.n_cst, in_dev, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v, bd.ai1,
-           bd.ao1, 1);
-    LAUNCH(ctx, TAG_TRANSCRIPT, k_load_blindings, cdiv(B * m, 64), 64, s, B, m, ent_dev, bd.vb);
-    if ((rc = commit_launch(ctx, B * m, bd.v, bd.vb, m, m, m, bd.pts, m + 8, s))) return rc;
-    LAUNCH(ctx, TAG_ENCODE, k_encode_strided, cdiv(B * m, 64), 64, s, B * m, m, bd.pts, m + 8, bd.enc, encw, 0u);
     const size_t n_draws = 3 + 2 * (size_t)n1;
     if ((rc = dev_reserve(ctx, ctx->raw, (size_t)B * n_draws * 64))) return rc;
-    LAUNCH(ctx, TAG_RNG, k_tr_open, cdiv(B, 64), 64, s, B, m, n1, prefix, bd.enc, ent_dev, bd.vb, (u32*)ctx->raw.p, bd.tr, bd.rng);
-    LAUNCH(ctx, TAG_RNG, k_reduce_draws, cdiv((u32)(B * n_draws), 128), 128, s, B, n1, (const u32*)ctx->raw.p, bd.ai1, bd.ao1, bd.s1);
+    hipStream_t main_s = s;
+    {
+        hipStream_t s = ctx->side;  // opening stage
+        // NOTE the opening stage does NOT wait for the caller's stream: in_dev / ent_dev must be complete when the call is
+        // made (include/bbp.h).  Waiting on the caller's stream tail would serialise it behind the previous call's heavy stage.
+        if (ctx->ev_done_valid[par]) BBP_HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_done[par], 0));
+        LAUNCH(ctx, TAG_WITNESS, k_fill_mimc, cdiv(B * BBP_MIMC_ROUNDS, 64), 64, s, B, c.n_cst, ctx->mimc_c, bd.cst);
+        LAUNCH(ctx, TAG_WITNESS, k_witness, cdiv(B, 64), 64, s, B, N, n1, c.n_cst, in_dev, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v, bd.ai1,
+               bd.ao1, 1);
+        LAUNCH(ctx, TAG_TRANSCRIPT, k_load_blindings, cdiv(B * m, 64), 64, s, B, m, ent_dev, bd.vb);
+        if ((rc = commit_launch(ctx, B * m, bd.v, bd.vb, m, m, m, bd.pts, m + 8, s))) return rc;
+        LAUNCH(ctx, TAG_ENCODE, k_encode_strided, cdiv(B * m, 64), 64, s, B * m, m, bd.pts, m + 8, bd.enc, encw, 0u);
+        LAUNCH(ctx, TAG_RNG, k_tr_open, cdiv(B, 64), 64, s, B, m, n1, prefix, bd.enc, ent_dev, bd.vb, (u32*)ctx->raw.p, bd.tr, bd.rng);
+        LAUNCH(ctx, TAG_RNG, k_reduce_draws, cdiv((u32)(B * n_draws), 128), 128, s, B, n1, (const u32*)ctx->raw.p, bd.ai1, bd.ao1, bd.s1);
+        BBP_HIP_TRY(ctx, hipEventRecord(ctx->ev_open[par], s));
+        ctx->ev_open_valid[par] = true;
+    }
+    BBP_HIP_TRY(ctx, hipStreamWaitEvent(main_s, ctx->ev_open[par], 0));
     // A_I1, A_O1, S1 -> pts[m + 0..2] (strided output: launch per commitment with an output view)
     if ((rc = dev_reserve(ctx, ctx->pts, sizeof(ge) * (size_t)B * 3))) return rc;
     ge* tmp = static_cast<ge*>(ctx->pts.p);
@@ -779,6 +795,9 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
     }
     LAUNCH(ctx, TAG_TRANSCRIPT, k_ipa_final, cdiv(B, 64), 64, s, B, m, bd.enc, bd.tr, bd.misc, bd.a, bd.b);
     LAUNCH(ctx, TAG_TRANSCRIPT, k_assemble, cdiv(B, 64), 64, s, B, m, bd.enc, bd.misc, out_dev);
+    BBP_HIP_TRY(ctx, hipEventRecord(ctx->ev_done[par], s));
+    ctx->ev_done_valid[par] = true;
+    ctx->last_par = par;
     return BBP_OK;
 }
 
@@ -788,7 +807,7 @@ int32_t debug_read_misc(bbp_ctx* ctx, u32 B, u32 N, u32 proof, uint8_t* out) {
     int32_t rc = circuit_get(ctx, N, &cp);
     if (rc) return rc;
     BatchDev bd;
-    if ((rc = batch_reserve(ctx, B, *cp, bd))) return rc;
+    if ((rc = batch_reserve(ctx, B, *cp, bd, ctx->last_par))) return rc;
     BBP_HIP_TRY(ctx, hipMemcpy(out, bd.misc + (size_t)proof * MS_COUNT, MS_COUNT * 32, hipMemcpyDeviceToHost));
     return BBP_OK;
 }

@@ -90,6 +90,12 @@ extern "C" int32_t bbp_init(int32_t device, bbp_ctx** out) {
         return BBP_ERR_DEVICE;
     }
     BBP_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    BBP_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) {
+        BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_in[i], hipEventDisableTiming));
+        BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_open[i], hipEventDisableTiming));
+        BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_done[i], hipEventDisableTiming));
+    }
 
     // --- host hashing -----------------------------------------------------------------------------
     const size_t n_uniform = 2 * BBP_GENS_CAPACITY + 1;
@@ -128,10 +134,16 @@ extern "C" int32_t bbp_init(int32_t device, bbp_ctx** out) {
 extern "C" void bbp_free(bbp_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    void* ptrs[] = {ctx->gens, ctx->wtable, ctx->comb, ctx->mimc_c, ctx->scal.p, ctx->idx.p, ctx->sorted.p, ctx->pts.p, ctx->enc.p, ctx->misc.p, ctx->batch.p, ctx->io_in.p, ctx->io_out.p, ctx->io_ent.p, ctx->raw.p};
+    (void)hipDeviceSynchronize();
+    void* ptrs[] = {ctx->gens, ctx->wtable, ctx->comb, ctx->mimc_c, ctx->scal.p, ctx->idx.p, ctx->sorted.p, ctx->pts.p, ctx->enc.p, ctx->misc.p, ctx->batch.p, ctx->io_in.p, ctx->io_out.p, ctx->io_ent.p, ctx->raw.p, ctx->batch1.p};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    for (int i = 0; i < 2; i++) {
+        if (ctx->ev_in[i]) (void)hipEventDestroy(ctx->ev_in[i]);
+        if (ctx->ev_open[i]) (void)hipEventDestroy(ctx->ev_open[i]);
+        if (ctx->ev_done[i]) (void)hipEventDestroy(ctx->ev_done[i]);
+    }
+    if (ctx->side) (void)hipStreamDestroy(ctx->side);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
