@@ -30,6 +30,7 @@ SIGNATURES = {
     "bbp_prove_batch_dev": (_i32, [_vp, _u32, _u32, _vp, _vp, _vp, _vp]),
     "bbp_verify_batch_dev": (_i32, [_vp, _u32, _u32, _vp, _vp, _vp, _vp]),
     "bbp_debug_challenges": (_i32, [_vp, _u32, _u32, _u32, _vp]),
+    "bbp_ubench": (_i32, [_vp, _i32, _u32, _u32, ctypes.POINTER(ctypes.c_double)]),
     "bbp_set_profiling": (_i32, [_vp, _i32]),
     "bbp_last_timings": (_i32, [_vp, _vp, _u32, ctypes.POINTER(_u32)]),
 }
@@ -165,6 +166,11 @@ class Context:
         names = ["y", "z", "u", "x", "w", "y_inv", "t1", "t2", "t3", "t4", "t5", "t6", "tb1", "tb2", "tb3", "tb4", "tb5", "tb6",
                  "t_x", "t_x_blinding", "e_blinding", "uj", "uji", "a", "b", "r", "allinv", "wc", "delta"]
         return {n: raw[32 * i:32 * i + 32].hex() for i, n in enumerate(names)}
+
+    def ubench(self, kind, blocks=4096, iters=2000):
+        v = ctypes.c_double()
+        self._check(lib.bbp_ubench(self._h, kind, blocks, iters, ctypes.byref(v)))
+        return v.value
 
     def set_profiling(self, on):
         self._check(lib.bbp_set_profiling(self._h, 1 if on else 0))

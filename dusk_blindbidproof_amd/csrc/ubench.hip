@@ -1,0 +1,86 @@
+// Integer-ALU roofline microbenchmarks (diagnostic ABI, include/bbp.h bbp_ubench): the blind-bid path is bound by 32-bit
+// integer multiply issue (v_mad_u64_u32), not by HBM, so the honest ceiling for K1 is "field multiplications per second the
+// chip can issue", measured here with register-resident dependent chains at full occupancy.
+//   kind 0: raw v_mad_u64_u32 chain (4 independent accumulators per lane)      -> mads/s
+//   kind 1: fe_mul chains (2 per lane)                                            -> field multiplications/s
+//   kind 2: fe_sq chains                                                          -> field squarings/s
+//   kind 3: ge_madd chain (register-resident cached point, no memory)            -> mixed additions/s
+//   kind 4: sc_montmul chains                                                     -> Montgomery products mod l /s
+#include "context.h"
+
+namespace bbp {
+
+__global__ __launch_bounds__(256) void k_ubench(int kind, u32 iters, u32* __restrict__ sink) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 acc = 0;
+    if (kind == 0) {
+        u64 a0 = t, a1 = t + 1, a2 = t + 2, a3 = t + 3;
+        u32 x = t * 2654435761u + 1, y = t ^ 0x9e3779b9u;
+        for (u32 i = 0; i < iters; i++) {
+            a0 = (u64)x * (u32)a0 + a1;
+            a1 = (u64)y * (u32)a1 + a2;
+            a2 = (u64)x * (u32)a2 + a3;
+            a3 = (u64)y * (u32)a3 + a0;
+        }
+        acc = (u32)(a0 ^ a1 ^ a2 ^ a3);
+    } else if (kind == 1 || kind == 2) {
+        fe a = fe_d(), b = fe_sqrt_m1();
+        a.v[0] ^= t;
+        b.v[1] ^= t;
+        for (u32 i = 0; i < iters; i++) {
+            if (kind == 1) {
+                a = fe_mul(a, b);
+                b = fe_mul(b, a);
+            } else {
+                a = fe_sq(a);
+                b = fe_sq(b);
+            }
+        }
+        acc = a.v[0] ^ b.v[3];
+    } else if (kind == 3) {
+        ge p = ge_basepoint();
+        p.X.v[0] ^= t;
+        ge_niels n;
+        n.ypx = fe_d();
+        n.ymx = fe_d2();
+        n.xy2d = fe_sqrt_m1();
+        for (u32 i = 0; i < iters; i++) p = ge_madd(p, n);
+        acc = p.X.v[0] ^ p.T.v[2];
+    } else {
+        sc a = sc_rr(), b = sc_r();
+        a.v[0] ^= (t & 0xff);
+        for (u32 i = 0; i < iters; i++) {
+            a = sc_montmul(a, b);
+            b = sc_montmul(b, a);
+        }
+        acc = a.v[0] ^ b.v[1];
+    }
+    sink[t] = acc;
+}
+
+}  // namespace bbp
+
+using namespace bbp;
+
+// Runs `blocks` x 256 lanes x `iters` iterations; *ops_per_sec = operations/s (ops per iteration per lane: 4,2,2,1,2).
+extern "C" int32_t bbp_ubench(bbp_ctx* ctx, int32_t kind, uint32_t blocks, uint32_t iters, double* ops_per_sec) {
+    if (!ctx || !ops_per_sec || kind < 0 || kind > 4 || blocks == 0) return BBP_ERR_BAD_ARG;
+    BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int32_t rc = dev_reserve(ctx, ctx->misc, (size_t)blocks * 256 * 4);
+    if (rc) return rc;
+    hipEvent_t a, b;
+    BBP_HIP_TRY(ctx, hipEventCreate(&a));
+    BBP_HIP_TRY(ctx, hipEventCreate(&b));
+    hipLaunchKernelGGL(k_ubench, dim3(blocks), dim3(256), 0, ctx->stream, kind, iters / 8 + 1, (u32*)ctx->misc.p);  // warm-up
+    BBP_HIP_TRY(ctx, hipEventRecord(a, ctx->stream));
+    hipLaunchKernelGGL(k_ubench, dim3(blocks), dim3(256), 0, ctx->stream, kind, iters, (u32*)ctx->misc.p);
+    BBP_HIP_TRY(ctx, hipEventRecord(b, ctx->stream));
+    BBP_HIP_TRY(ctx, hipEventSynchronize(b));
+    float ms = 0;
+    BBP_HIP_TRY(ctx, hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    const double per_iter[5] = {4, 2, 2, 1, 2};
+    *ops_per_sec = per_iter[kind] * (double)blocks * 256.0 * (double)iters / (ms * 1e-3);
+    return BBP_OK;
+}

@@ -111,6 +111,10 @@ int32_t bbp_verify_batch_dev(bbp_ctx* ctx, uint32_t B, uint32_t N, const void* i
  * y z u x w y^-1 t1..t6 tb1..tb6 t_x t_x~ e~ ... (MiscSlot order in csrc/batch.h), 32 x 32 bytes. */
 int32_t bbp_debug_challenges(bbp_ctx* ctx, uint32_t B, uint32_t N, uint32_t proof, uint8_t* out32x32);
 
+/* Integer-ALU roofline microbenchmarks (register-resident chains, no memory): kind 0 = v_mad_u64_u32, 1 = field multiply,
+ * 2 = field square, 3 = mixed point addition, 4 = Montgomery product mod l.  *ops_per_sec receives operations per second. */
+int32_t bbp_ubench(bbp_ctx* ctx, int32_t kind, uint32_t blocks, uint32_t iters, double* ops_per_sec);
+
 /* Per-kernel device timings: with profiling on, every kernel launch is bracketed by HIP events on its launch stream.
  * bbp_last_timings synchronises, drains them as (tag, microseconds) float pairs (tags: 1 = MSM kernel, 2 = encode, ...)
  * and reports the number of floats written in *n. */
