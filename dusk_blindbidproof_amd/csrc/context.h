@@ -20,6 +20,7 @@ constexpr int MSM_K = 1 << (MSM_C - 1);   // 1024 buckets (|digit| = 1..1024)
 constexpr int MSM_T = 128;                // threads per MSM workgroup (2 wavefronts)
 constexpr int MSM_G = MSM_K / MSM_T;      // 8 consecutive buckets per lane
 constexpr int MSM_LOG_G = 3;
+constexpr int GE_WORDS = sizeof(ge) / 4;  // 40: a point in registers / LDS / scratch
 
 struct DevBuf {
     void* p = nullptr;
@@ -39,8 +40,8 @@ struct bbp_ctx {
     std::string err;
     // resident tables
     bbp::ge* gens = nullptr;           // [BBP_NUM_BASES] extended points: B_blinding, G[2048], H[2048], B
-    bbp::ge_niels* wtable = nullptr;   // [BBP_NUM_BASES * MSM_W] affine cached 2^(11 j) * P_i
-    bbp::ge_niels* comb = nullptr;     // [2][64][8] radix-16 comb for B and B_blinding (small commits)
+    bbp::niels_packed* wtable = nullptr;   // [BBP_NUM_BASES * MSM_W] affine cached 2^(11 j) * P_i
+    bbp::niels_packed* comb = nullptr;     // [2][64][8] radix-16 comb for B and B_blinding (small commits)
     bbp::sc* mimc_c = nullptr;         // [90]
     uint8_t gens_enc_host_valid = 0;
     std::vector<uint8_t> mimc_host;    // 90 * 32

@@ -20,18 +20,37 @@ namespace bbp {
 __device__ __forceinline__ void lds_put(u32* stage, int t, const ge& p) {
     const u32* w = reinterpret_cast<const u32*>(&p);
 #pragma unroll
-    for (int i = 0; i < 32; i++) stage[i * MSM_T + t] = w[i];
+    for (int i = 0; i < GE_WORDS; i++) stage[i * MSM_T + t] = w[i];
 }
 
 __device__ __forceinline__ ge lds_get(const u32* stage, int t) {
     ge p;
     u32* w = reinterpret_cast<u32*>(&p);
 #pragma unroll
-    for (int i = 0; i < 32; i++) w[i] = stage[i * MSM_T + t];
+    for (int i = 0; i < GE_WORDS; i++) w[i] = stage[i * MSM_T + t];
     return p;
 }
 
-__device__ __forceinline__ ge_niels load_niels(const ge_niels* __restrict__ tab, u32 entry) {
+__device__ __forceinline__ niels_packed load_raw(const niels_packed* __restrict__ tab, u32 entry) {
+    const uint4* p = reinterpret_cast<const uint4*>(tab + (entry & 0x7fffffffu));
+    uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4], q5 = p[5];
+    niels_packed r = {{q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w,
+                       q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w}};
+    return r;
+}
+
+// packed row -> limbs; a negative digit uses -(x, y) = (-x, y): swap y+x / y-x and negate 2dxy
+__device__ __forceinline__ ge_niels unpack_niels(const niels_packed& r, u32 neg) {
+    ge_niels n;
+    fe a = fe_fromwords(r.w), b = fe_fromwords(r.w + 8), c = fe_fromwords(r.w + 16);
+    n.ypx = fe_select(a, b, neg != 0);
+    n.ymx = fe_select(b, a, neg != 0);
+    n.xy2d = fe_select(c, fe_neg(c), neg != 0);
+    return n;
+}
+
+// 96-byte packed table entry -> limbs (unpacking is ~90 ALU ops against ~2500 for the addition it feeds)
+__device__ __forceinline__ ge_niels load_niels(const niels_packed* __restrict__ tab, u32 entry) {
     const uint4* p = reinterpret_cast<const uint4*>(tab + (entry & 0x7fffffffu));
     uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4], q5 = p[5];
     ge_niels n;
@@ -47,6 +66,12 @@ __device__ __forceinline__ ge_niels load_niels(const ge_niels* __restrict__ tab,
     n.ymx = b;
     return n;
 }
+
+// The cold phases (bucket fold, cross-lane reduction) call ONE out-of-line copy of the point addition / doubling: inlining
+// them at seven sites made the kernel 124 KB, and with workgroups of a CU in different phases the 64 KB instruction cache
+// thrashed under the hot mixed-addition loop (measured: that loop ran 1.7x slower than the same code in isolation).
+__device__ __noinline__ void ge_add_nc(ge& r, const ge& a, const ge& b) { r = ge_add(a, b); }
+__device__ __noinline__ void ge_dbl_nc(ge& r, const ge& a) { r = ge_dbl(a); }
 
 // signed-digit walk over one scalar; calls f(j, magnitude, negative) for every non-zero digit
 template <class F>
@@ -69,13 +94,13 @@ __device__ __forceinline__ void for_each_digit(const u32 (&s)[8], F&& f) {
 }
 
 __global__ __launch_bounds__(MSM_T) void k_msm(const u32* __restrict__ scalars, const u32* __restrict__ base_idx_sets, u32 n,
-                                                u32 n_idx_sets, const ge_niels* __restrict__ wtable,
+                                                u32 n_idx_sets, const niels_packed* __restrict__ wtable,
                                                 u32* __restrict__ sorted_all, ge* __restrict__ bsum_all, ge* __restrict__ psum_all,
                                                 ge* __restrict__ out) {
     __shared__ u32 cnt[MSM_K + 1];
     __shared__ u32 cursor[MSM_K + 1];
     __shared__ u32 part[MSM_T];
-    __shared__ u32 stage[32 * MSM_T];
+    __shared__ u32 stage[GE_WORDS * MSM_T];
     const int tid = threadIdx.x;
     const size_t msm = blockIdx.x;
     const u32* sbase = scalars + msm * (size_t)n * 8;
@@ -153,7 +178,11 @@ __global__ __launch_bounds__(MSM_T) void k_msm(const u32* __restrict__ scalars, 
         u32 k = lo, kend = cursor[k];
         ge* dest = (cursor[k - 1] < c0) ? &psum[tid] : &bsum[k - 1];
         ge acc = ge_identity();
-        ge_niels nxt = load_niels(wtable, sorted[c0]);
+        // software pipeline, two deep: the entry index is fetched two iterations ahead and the 96-byte table row one
+        // iteration ahead, so neither load is waited for before a full mixed addition (~2000 instructions) has run
+        u32 ent_cur = sorted[c0];
+        u32 ent_nxt = (c0 + 1 < c1) ? sorted[c0 + 1] : 0u;
+        niels_packed raw = load_raw(wtable, ent_cur);
         for (u32 e = c0; e < c1; e++) {
             if (e == kend) {  // crossed into the next non-empty bucket
                 *dest = acc;
@@ -161,8 +190,10 @@ __global__ __launch_bounds__(MSM_T) void k_msm(const u32* __restrict__ scalars, 
                 do { k++; kend = cursor[k]; } while (kend == e);
                 dest = &bsum[k - 1];
             }
-            ge_niels cur = nxt;
-            if (e + 1 < c1) nxt = load_niels(wtable, sorted[e + 1]);
+            ge_niels cur = unpack_niels(raw, ent_cur >> 31);
+            ent_cur = ent_nxt;
+            if (e + 1 < c1) raw = load_raw(wtable, ent_cur);
+            if (e + 2 < c1) ent_nxt = sorted[e + 2];
             acc = ge_madd(acc, cur);
         }
         *dest = acc;
@@ -176,17 +207,17 @@ __global__ __launch_bounds__(MSM_T) void k_msm(const u32* __restrict__ scalars, 
         const u32 k = tid * MSM_G + r;
         const u32 kend = cursor[k], kbeg = cursor[k - 1];
         if (kbeg != kend) {
-            running = ge_add(running, bsum[k - 1]);
+            ge_add_nc(running, running, bsum[k - 1]);
             // chunks that START strictly inside this bucket carry a partial sum for it
             u32 t = (u32)(((u64)kbeg * MSM_T) / E);
             for (; t < MSM_T; t++) {
                 const u32 ct = (u32)(((u64)t * E) / MSM_T);
                 if (ct >= kend) break;
                 const u32 ct1 = (u32)(((u64)(t + 1) * E) / MSM_T);
-                if (ct > kbeg && ct1 > ct) running = ge_add(running, psum[t]);
+                if (ct > kbeg && ct1 > ct) ge_add_nc(running, running, psum[t]);
             }
         }
-        total = ge_add(total, running);
+        ge_add_nc(total, total, running);
     }
 
     // E. cross-lane fold: R = sum_t total_t + 8 * sum_{t>=1} suffix_t, suffix_t = sum_{u>=t} running_u
@@ -198,7 +229,7 @@ __global__ __launch_bounds__(MSM_T) void k_msm(const u32* __restrict__ scalars, 
         if (has) other = lds_get(stage, tid + d);
         __syncthreads();
         if (has) {
-            running = ge_add(running, other);
+            ge_add_nc(running, running, other);
             lds_put(stage, tid, running);
         }
         __syncthreads();
@@ -206,15 +237,15 @@ __global__ __launch_bounds__(MSM_T) void k_msm(const u32* __restrict__ scalars, 
     ge x = total;
     if (tid >= 1) {
         ge s = running;
-        for (int i = 0; i < MSM_LOG_G; i++) s = ge_dbl(s);
-        x = ge_add(x, s);
+        for (int i = 0; i < MSM_LOG_G; i++) ge_dbl_nc(s, s);
+        ge_add_nc(x, x, s);
     }
     lds_put(stage, tid, x);
     __syncthreads();
     for (int d = MSM_T / 2; d >= 1; d >>= 1) {
         if (tid < d) {
             ge other = lds_get(stage, tid + d);
-            x = ge_add(x, other);
+            ge_add_nc(x, x, other);
             lds_put(stage, tid, x);
         }
         __syncthreads();

@@ -13,9 +13,21 @@ struct ge {  // extended: x = X/Z, y = Y/Z, T = XY/Z
     fe X, Y, Z, T;
 };
 
-struct ge_niels {  // affine (Z = 1) cached form for mixed addition: 96 bytes in the tables
+struct ge_niels {  // affine (Z = 1) cached form for mixed addition, in registers
     fe ypx, ymx, xy2d;
 };
+
+struct niels_packed {  // the same three field elements as canonical 8-word values: 96 bytes per table entry in HBM
+    u32 w[24];
+};
+
+BBP_HD niels_packed niels_pack(const ge_niels& n) {
+    niels_packed p;
+    fe_towords(p.w, n.ypx);
+    fe_towords(p.w + 8, n.ymx);
+    fe_towords(p.w + 16, n.xy2d);
+    return p;
+}
 
 BBP_HD ge ge_identity() {
     ge r;
@@ -96,8 +108,7 @@ BBP_HD ge ge_msub(const ge& p, const ge_niels& q) {
 BBP_HD ge ge_dbl(const ge& p) {
     fe a = fe_sq(p.X);
     fe b = fe_sq(p.Y);
-    fe zz = fe_sq(p.Z);
-    fe c = fe_add(zz, zz);
+    fe c = fe_sq2(p.Z);  // carried, so that f = c + g stays inside the multiply bounds
     fe h = fe_add(a, b);
     fe xy = fe_add(p.X, p.Y);
     fe e = fe_sub(h, fe_sq(xy));
@@ -156,37 +167,23 @@ BBP_HD_NOINLINE fe ge_encode_s(const ge& p) {
     fe y = fe_select(p.Y, ix0, rotate);
     fe den_inv = fe_select(den2, ench, rotate);
     y = fe_select(y, fe_neg(y), fe_isneg(fe_mul(x, z_inv)));
-    return fe_canon(fe_abs(fe_mul(den_inv, fe_sub(p.Z, y))));
+    return fe_abs(fe_mul(den_inv, fe_sub(p.Z, y)));
 }
 
-BBP_HD void ge_encode(uint8_t* out32, const ge& p) {
-    fe s = ge_encode_s(p);
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        out32[4 * i + 0] = (uint8_t)(s.v[i]);
-        out32[4 * i + 1] = (uint8_t)(s.v[i] >> 8);
-        out32[4 * i + 2] = (uint8_t)(s.v[i] >> 16);
-        out32[4 * i + 3] = (uint8_t)(s.v[i] >> 24);
-    }
-}
+BBP_HD void ge_encode_words(u32* out8, const ge& p) { fe_towords(out8, ge_encode_s(p)); }
 
-BBP_HD void ge_encode_words(u32* out8, const ge& p) {
-    fe s = ge_encode_s(p);
-#pragma unroll
-    for (int i = 0; i < 8; i++) out8[i] = s.v[i];
-}
+BBP_HD void ge_encode(uint8_t* out32, const ge& p) { fe_tobytes(out32, ge_encode_s(p)); }
 
 // RFC 9496 4.3.1 Decode from 8 LE words; false on any failure (non-canonical, negative, not on curve)
 BBP_HD_NOINLINE bool ge_decode_words(ge& out, const u32* w) {
-    fe s;
-#pragma unroll
-    for (int i = 0; i < 8; i++) s.v[i] = w[i];
-    // canonical (< p) and non-negative (even)
-    fe sc_ = fe_canon(s);
+    fe s = fe_fromwords(w);
+    // canonical (< p, bit 255 clear) and non-negative (even): re-encoding must give the same 8 words
+    u32 chk[8];
+    fe_towords(chk, s);
     u32 diff = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) diff |= sc_.v[i] ^ s.v[i];
-    bool ok = (diff == 0) && !(s.v[0] & 1u);
+    for (int i = 0; i < 8; i++) diff |= chk[i] ^ w[i];
+    bool ok = (diff == 0) && !(w[0] & 1u);
     fe ss = fe_sq(s);
     fe u1 = fe_sub(fe_one(), ss);
     fe u2 = fe_add(fe_one(), ss);

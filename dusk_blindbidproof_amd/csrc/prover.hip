@@ -139,7 +139,7 @@ __global__ void k_fill_mimc(u32 B, u32 n_cst, const sc* __restrict__ mimc, sc* _
 // ---------------------------------------------------------------------------------------------------------------
 // K2: Pedersen commitments through the radix-16 comb (64 signed digits per scalar, 8 cached multiples each)
 // ---------------------------------------------------------------------------------------------------------------
-__device__ ge comb_mul_add(ge acc, const ge_niels* __restrict__ comb_base, const sc& s) {
+__device__ ge comb_mul_add(ge acc, const niels_packed* __restrict__ comb_base, const sc& s) {
     u32 carry = 0;
     for (int j = 0; j < 64; j++) {
         u32 d = ((s.v[j >> 3] >> (4 * (j & 7))) & 15u) + carry;
@@ -166,7 +166,7 @@ __device__ ge comb_mul_add(ge acc, const ge_niels* __restrict__ comb_base, const
 
 // commitment c of proof p: values[p*stride_v + c], blindings[p*stride_b + c] -> out[p*out_stride + c]
 __global__ void k_commit(u32 count, u32 per_proof, const sc* __restrict__ values, const sc* __restrict__ blindings, u32 stride_v,
-                         u32 stride_b, const ge_niels* __restrict__ comb, ge* __restrict__ out, u32 out_stride) {
+                         u32 stride_b, const niels_packed* __restrict__ comb, ge* __restrict__ out, u32 out_stride) {
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= count) return;
     u32 p = t / per_proof, c = t % per_proof;
@@ -407,7 +407,7 @@ __global__ void k_tr_tblind(u32 B, merlin_transcript* __restrict__ rng, sc* __re
 }
 
 // T_k = t_k B + tb_k B~ for k in {1,3,4,5,6}: one lane per (proof, k)
-__global__ void k_commit_T(u32 B, const sc* __restrict__ misc, const ge_niels* __restrict__ comb, ge* __restrict__ pts, u32 pts_stride, u32 m) {
+__global__ void k_commit_T(u32 B, const sc* __restrict__ misc, const niels_packed* __restrict__ comb, ge* __restrict__ pts, u32 pts_stride, u32 m) {
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B * 5) return;
     u32 p = t / 5, k = t % 5;

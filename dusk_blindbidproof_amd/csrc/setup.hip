@@ -27,18 +27,18 @@ __global__ void k_derive_generators(const u32* __restrict__ uniform, ge* __restr
 }
 
 // thread i: table[i*W + j] = affine cached form of 2^(C j) * gens[i]
-__global__ void k_build_wtable(const ge* __restrict__ gens, ge_niels* __restrict__ table) {
+__global__ void k_build_wtable(const ge* __restrict__ gens, niels_packed* __restrict__ table) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= BBP_NUM_BASES) return;
     ge p = gens[i];
     for (int j = 0; j < MSM_W; j++) {
-        table[(size_t)i * MSM_W + j] = ge_to_niels(p, fe_invert(p.Z));
+        table[(size_t)i * MSM_W + j] = niels_pack(ge_to_niels(p, fe_invert(p.Z)));
         for (int k = 0; k < MSM_C; k++) p = ge_dbl(p);
     }
 }
 
 // radix-16 comb for the two Pedersen bases: comb[b][j][m-1] = m * 16^j * Base_b, m = 1..8, j = 0..63
-__global__ void k_build_comb(const ge* __restrict__ gens, ge_niels* __restrict__ comb) {
+__global__ void k_build_comb(const ge* __restrict__ gens, niels_packed* __restrict__ comb) {
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= 2 * 64) return;
     u32 b = t / 64, j = t % 64;
@@ -46,7 +46,7 @@ __global__ void k_build_comb(const ge* __restrict__ gens, ge_niels* __restrict__
     for (u32 k = 0; k < 4 * j; k++) p = ge_dbl(p);
     ge m = p;
     for (int k = 0; k < 8; k++) {
-        comb[((size_t)b * 64 + j) * 8 + k] = ge_to_niels(m, fe_invert(m.Z));
+        comb[((size_t)b * 64 + j) * 8 + k] = niels_pack(ge_to_niels(m, fe_invert(m.Z)));
         m = ge_add(m, p);
     }
 }
@@ -116,8 +116,8 @@ extern "C" int32_t bbp_init(int32_t device, bbp_ctx** out) {
     BBP_HIP_TRY(ctx, hipMalloc(&d_uniform, uniform.size()));
     BBP_HIP_TRY(ctx, hipMemcpyAsync(d_uniform, uniform.data(), uniform.size(), hipMemcpyHostToDevice, ctx->stream));
     BBP_HIP_TRY(ctx, hipMalloc(&ctx->gens, sizeof(ge) * BBP_NUM_BASES));
-    BBP_HIP_TRY(ctx, hipMalloc(&ctx->wtable, sizeof(ge_niels) * (size_t)BBP_NUM_BASES * MSM_W));
-    BBP_HIP_TRY(ctx, hipMalloc(&ctx->comb, sizeof(ge_niels) * 2 * 64 * 8));
+    BBP_HIP_TRY(ctx, hipMalloc(&ctx->wtable, sizeof(niels_packed) * (size_t)BBP_NUM_BASES * MSM_W));
+    BBP_HIP_TRY(ctx, hipMalloc(&ctx->comb, sizeof(niels_packed) * 2 * 64 * 8));
     BBP_HIP_TRY(ctx, hipMalloc(&ctx->mimc_c, sizeof(sc) * BBP_MIMC_ROUNDS));
     BBP_HIP_TRY(ctx, hipMemcpyAsync(ctx->mimc_c, ctx->mimc_host.data(), 32 * BBP_MIMC_ROUNDS, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_derive_generators, dim3((BBP_NUM_BASES + 63) / 64), dim3(64), 0, ctx->stream, d_uniform, ctx->gens);

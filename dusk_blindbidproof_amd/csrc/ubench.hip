@@ -1,17 +1,21 @@
 // Integer-ALU roofline microbenchmarks (diagnostic ABI, include/bbp.h bbp_ubench): the blind-bid path is bound by 32-bit
-// integer multiply issue (v_mad_u64_u32), not by HBM, so the honest ceiling for K1 is "field multiplications per second the
-// chip can issue", measured here with register-resident dependent chains at full occupancy.
+// integer multiply issue (v_mad_i64_i32 / v_mad_u64_u32), not by HBM, so the honest ceiling for K1 is "mixed point additions
+// per second the chip can issue", measured here with register-resident dependent chains and no memory traffic.
 //   kind 0: raw v_mad_u64_u32 chain (4 independent accumulators per lane)      -> mads/s
 //   kind 1: fe_mul chains (2 per lane)                                            -> field multiplications/s
 //   kind 2: fe_sq chains                                                          -> field squarings/s
 //   kind 3: ge_madd chain (register-resident cached point, no memory)            -> mixed additions/s
 //   kind 4: sc_montmul chains                                                     -> Montgomery products mod l /s
+#include <stdlib.h>
+
 #include "context.h"
 
 namespace bbp {
 
 __global__ __launch_bounds__(256) void k_ubench(int kind, u32 iters, u32* __restrict__ sink) {
+    extern __shared__ u32 occupancy_ballast[];  // dynamic LDS only throttles waves/SIMD (BBP_UBENCH_LDS)
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (iters == 0xffffffffu) occupancy_ballast[threadIdx.x] = t;
     u32 acc = 0;
     if (kind == 0) {
         u64 a0 = t, a1 = t + 1, a2 = t + 2, a3 = t + 3;
@@ -25,8 +29,8 @@ __global__ __launch_bounds__(256) void k_ubench(int kind, u32 iters, u32* __rest
         acc = (u32)(a0 ^ a1 ^ a2 ^ a3);
     } else if (kind == 1 || kind == 2) {
         fe a = fe_d(), b = fe_sqrt_m1();
-        a.v[0] ^= t;
-        b.v[1] ^= t;
+        a.v[0] ^= (i32)(t & 0xffff);
+        b.v[1] ^= (i32)(t & 0xffff);
         for (u32 i = 0; i < iters; i++) {
             if (kind == 1) {
                 a = fe_mul(a, b);
@@ -36,16 +40,16 @@ __global__ __launch_bounds__(256) void k_ubench(int kind, u32 iters, u32* __rest
                 b = fe_sq(b);
             }
         }
-        acc = a.v[0] ^ b.v[3];
+        acc = (u32)(a.v[0] ^ b.v[3]);
     } else if (kind == 3) {
         ge p = ge_basepoint();
-        p.X.v[0] ^= t;
+        p.X.v[0] ^= (i32)(t & 0xffff);
         ge_niels n;
         n.ypx = fe_d();
         n.ymx = fe_d2();
         n.xy2d = fe_sqrt_m1();
         for (u32 i = 0; i < iters; i++) p = ge_madd(p, n);
-        acc = p.X.v[0] ^ p.T.v[2];
+        acc = (u32)(p.X.v[0] ^ p.T.v[2]);
     } else {
         sc a = sc_rr(), b = sc_r();
         a.v[0] ^= (t & 0xff);
@@ -71,9 +75,11 @@ extern "C" int32_t bbp_ubench(bbp_ctx* ctx, int32_t kind, uint32_t blocks, uint3
     hipEvent_t a, b;
     BBP_HIP_TRY(ctx, hipEventCreate(&a));
     BBP_HIP_TRY(ctx, hipEventCreate(&b));
-    hipLaunchKernelGGL(k_ubench, dim3(blocks), dim3(256), 0, ctx->stream, kind, iters / 8 + 1, (u32*)ctx->misc.p);  // warm-up
+    const char* lds_env = getenv("BBP_UBENCH_LDS");
+    const unsigned lds = lds_env ? (unsigned)atoi(lds_env) : 0u;
+    hipLaunchKernelGGL(k_ubench, dim3(blocks), dim3(256), lds, ctx->stream, kind, iters / 8 + 1, (u32*)ctx->misc.p);  // warm-up
     BBP_HIP_TRY(ctx, hipEventRecord(a, ctx->stream));
-    hipLaunchKernelGGL(k_ubench, dim3(blocks), dim3(256), 0, ctx->stream, kind, iters, (u32*)ctx->misc.p);
+    hipLaunchKernelGGL(k_ubench, dim3(blocks), dim3(256), lds, ctx->stream, kind, iters, (u32*)ctx->misc.p);
     BBP_HIP_TRY(ctx, hipEventRecord(b, ctx->stream));
     BBP_HIP_TRY(ctx, hipEventSynchronize(b));
     float ms = 0;

@@ -14,9 +14,10 @@ extern "C" {
 
 // op: 0 add, 1 sub, 2 mul, 3 sq, 4 invert, 5 canon(a), 6 neg, 7 pow22523, 8 mul_small(a, b[0])
 void hc_fe_op(int op, const uint8_t* a32, const uint8_t* b32, uint8_t* out32) {
-    fe a, b, r;
-    ld(a.v, a32, 8);
-    ld(b.v, b32, 8);
+    u32 wa[8], wb[8];
+    ld(wa, a32, 8);
+    ld(wb, b32, 8);
+    fe a = fe_fromwords(wa), b = fe_fromwords(wb), r;  // bit 255 ignored
     switch (op) {
         case 0: r = fe_add(a, b); break;
         case 1: r = fe_sub(a, b); break;
@@ -26,7 +27,16 @@ void hc_fe_op(int op, const uint8_t* a32, const uint8_t* b32, uint8_t* out32) {
         case 5: r = a; break;
         case 6: r = fe_neg(a); break;
         case 7: r = fe_pow22523(a); break;
-        default: r = fe_mul_small(a, b.v[0] & 0x3ffffffu); break;
+        case 8: r = fe_mul_small(a, wb[0] & 0x3ffffffu); break;
+        case 9: r = fe_sq2(a); break;
+        case 10: {  // worst-case operand growth the point formulas produce: three-term sums into a multiply, twice
+            fe m1 = fe_mul(a, b), m2 = fe_sq(b), m3 = fe_mul(b, fe_sq(a));
+            fe s = fe_add(fe_add(m1, m1), m2), d = fe_sub(fe_sub(m3, m2), m1);
+            r = fe_mul(s, d);
+            r = fe_sq(fe_sub(fe_add(r, m1), m3));
+            break;
+        }
+        default: r = fe_zero(); break;
     }
     fe_tobytes(out32, r);
 }

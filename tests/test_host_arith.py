@@ -32,19 +32,28 @@ def test_field_ops(lib):
         out = ctypes.create_string_buffer(32)
         lib.hc_fe_op(op, b32(a), b32(b), out)
         return int.from_bytes(out.raw, "little")
-    vals = EDGE + [rnd.getrandbits(256) for _ in range(200)]
-    for a in vals:
-        for b in rnd.sample(vals, 5) + EDGE[:4] + [2**256 - 1, 2**256 - 38]:
-            assert fe_op(0, a, b) == (a + b) % P
-            assert fe_op(1, a, b) == (a - b) % P
-            assert fe_op(2, a, b) == (a * b) % P
-            assert fe_op(8, a, b) == (a * (b & 0x3ffffff)) % P
-        assert fe_op(3, a) == a * a % P
-        assert fe_op(5, a) == a % P
-        assert fe_op(6, a) == (-a) % P
-    for a in vals[:40]:
-        assert fe_op(4, a) == pow(a % P, P - 2, P)
-        assert fe_op(7, a) == pow(a % P, (P - 5) // 8, P)
+    M = (1 << 255) - 1  # the loader ignores bit 255, like dalek's FieldElement::from_bytes
+    limb_edges = [(1 << 26) - 1, ((1 << 25) - 1) << 26, M, M - 18, M - 19, M - 20, (1 << 255) - (1 << 230), sum(1 << o for o in (25, 50, 76, 101, 127, 152, 178, 203, 229, 254))]
+    vals = EDGE + limb_edges + [rnd.getrandbits(256) for _ in range(200)]
+    for a0 in vals:
+        a = a0 & M
+        for b0 in rnd.sample(vals, 5) + EDGE[:4] + [2**256 - 1, 2**256 - 38] + limb_edges[:3]:
+            b = b0 & M
+            assert fe_op(0, a0, b0) == (a + b) % P
+            assert fe_op(1, a0, b0) == (a - b) % P
+            assert fe_op(2, a0, b0) == (a * b) % P
+            assert fe_op(8, a0, b0) == (a * (b0 & 0x3ffffff)) % P
+            m1, m2, m3 = a * b % P, b * b % P, b * a * a % P
+            r = (2 * m1 + m2) * (m3 - m2 - m1) % P
+            assert fe_op(10, a0, b0) == pow(r + m1 - m3, 2, P)
+        assert fe_op(3, a0) == a * a % P
+        assert fe_op(9, a0) == 2 * a * a % P
+        assert fe_op(5, a0) == a % P
+        assert fe_op(6, a0) == (-a) % P
+    for a0 in vals[:40]:
+        a = a0 & M
+        assert fe_op(4, a0) == pow(a % P, P - 2, P)
+        assert fe_op(7, a0) == pow(a % P, (P - 5) // 8, P)
 
 
 def test_scalar_ops(lib):
