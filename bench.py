@@ -57,7 +57,9 @@ def timed(wl, ctx, torch, dist, world, steps, stream):
 def roofline(wl, timings, steps):
     dom = [us for tag, us in timings if tag == wl.dominant_tag]
     avg_us = sum(dom) / max(len(dom), 1)
-    alg_per_launch = wl.alg_bytes_per_step / wl.dominant_launches_per_step
+    # algorithmic bytes of the step's dominant-kernel work, spread over the launches that were actually observed
+    # (the engine may cut a batch into half-batches on two streams, doubling the launch count)
+    alg_per_launch = wl.alg_bytes_per_step * steps / max(len(dom), 1)
     achieved = alg_per_launch / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
             "traffic": wl.measured_traffic_bytes, "kernel": wl.dominant_kernel, "avg_launch_us": avg_us, "launches": len(dom),

@@ -33,6 +33,8 @@ struct bbp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;            // opening stage of the prover pipeline (prover.hip)
+    hipStream_t main2 = nullptr;           // second half-batch of the heavy stage
+    hipEvent_t ev_join = nullptr;
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_open[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     bool ev_done_valid[2] = {false, false}, ev_open_valid[2] = {false, false};
     uint32_t seq = 0;
@@ -46,7 +48,7 @@ struct bbp_ctx {
     uint8_t gens_enc_host_valid = 0;
     std::vector<uint8_t> mimc_host;    // 90 * 32
     // grow-only scratch
-    bbp::DevBuf scal, idx, sorted, pts, enc, misc, batch, batch1, io_in, io_out, io_ent, raw;
+    bbp::DevBuf scal, idx, sorted, sorted2, pts, pts2, enc, misc, batch, batch1, io_in, io_out, io_ent, raw;
     std::map<uint32_t, void*> circuits;  // N -> CircuitDev* (compiled blind-bid circuit tables on the device)
     std::vector<float> timings;
     // optional per-kernel HIP-event timing (bbp_set_profiling): (tag, start, stop) on the launch stream
@@ -104,7 +106,7 @@ struct ScopedEvent {  // records start now, stop at scope exit, when profiling i
 // msm.hip
 // base_idx_dev holds n_idx_sets lists of n_terms indices; MSM number i uses list (i % n_idx_sets)
 int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* scalars_dev, const u32* base_idx_dev,
-                   ge* out_points_dev, hipStream_t stream, uint32_t n_idx_sets = 1);
+                   ge* out_points_dev, hipStream_t stream, uint32_t n_idx_sets = 1, int scratch_slot = 0);
 int32_t encode_launch(bbp_ctx* ctx, uint32_t n, const ge* pts_dev, uint8_t* out32_dev, hipStream_t stream);
 size_t msm_scratch_bytes(uint32_t n_msm, uint32_t n_terms);
 

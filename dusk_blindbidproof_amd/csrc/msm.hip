@@ -271,18 +271,19 @@ size_t msm_scratch_bytes(uint32_t n_msm, uint32_t n_terms) {
 }
 
 int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* scalars_dev, const u32* base_idx_dev,
-                   ge* out_points_dev, hipStream_t stream, uint32_t n_idx_sets) {
+                   ge* out_points_dev, hipStream_t stream, uint32_t n_idx_sets, int scratch_slot) {
     if (n_msm == 0) return BBP_OK;
     if (n_terms == 0 || n_terms > 65535u) {
         ctx->err = "msm_launch: n_terms out of range";
         return BBP_ERR_BAD_ARG;
     }
-    int32_t rc = dev_reserve(ctx, ctx->sorted, msm_scratch_bytes(n_msm, n_terms));
+    DevBuf& scratch = scratch_slot ? ctx->sorted2 : ctx->sorted;  // one scratch area per concurrently running stream
+    int32_t rc = dev_reserve(ctx, scratch, msm_scratch_bytes(n_msm, n_terms));
     if (rc) return rc;
-    ge* bsum = reinterpret_cast<ge*>(static_cast<u8*>(ctx->sorted.p) + msm_sorted_bytes(n_msm, n_terms));
+    ge* bsum = reinterpret_cast<ge*>(static_cast<u8*>(scratch.p) + msm_sorted_bytes(n_msm, n_terms));
     ScopedEvent ev(ctx, TAG_MSM, stream);
     hipLaunchKernelGGL(k_msm, dim3(n_msm), dim3(MSM_T), 0, stream, scalars_dev, base_idx_dev, n_terms, n_idx_sets, ctx->wtable,
-                       (u32*)ctx->sorted.p, bsum, bsum + (size_t)n_msm * MSM_K, out_points_dev);
+                       (u32*)scratch.p, bsum, bsum + (size_t)n_msm * MSM_K, out_points_dev);
     BBP_HIP_TRY(ctx, hipGetLastError());
     return BBP_OK;
 }

@@ -729,6 +729,9 @@ static merlin_transcript prover_prefix() {
 
 static inline u32 cdiv(u32 a, u32 b) { return (a + b - 1) / b; }
 
+static BatchDev batch_view(const BatchDev& bd, const CircuitDev& c, u32 first);
+static int32_t prove_heavy(bbp_ctx* ctx, const CircuitDev& c, const BatchDev& bd, u32 B, u8* out_dev, hipStream_t s, int slot);
+
 // in_dev: B * (7*32 + N*32 + 8) ; ent_dev: B * (32 m + 32) ; out_dev: B * (1121 + 32 m).  All device pointers.
 int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* ent_dev, u8* out_dev, hipStream_t s) {
     const CircuitDev* cp;
@@ -764,13 +767,49 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
         BBP_HIP_TRY(ctx, hipEventRecord(ctx->ev_open[par], s));
         ctx->ev_open_valid[par] = true;
     }
+    // HEAVY stage.  The batch is cut into two halves that run the same kernel sequence on two streams (the caller's and
+    // the context's second main stream): while one half sits in a latency-bound step (the per-round transcript + scalar
+    // inversion in k_ipa_round, the small encode / commit kernels) the other half's MSM keeps the CUs busy.
+    const u32 halves = B >= 128 ? 2u : 1u;
+    const u32 B0 = halves == 2 ? B / 2 : B;
     BBP_HIP_TRY(ctx, hipStreamWaitEvent(main_s, ctx->ev_open[par], 0));
+    if ((rc = prove_heavy(ctx, c, batch_view(bd, c, 0), B0, out_dev, main_s, 0))) return rc;
+    if (halves == 2) {
+        BBP_HIP_TRY(ctx, hipStreamWaitEvent(ctx->main2, ctx->ev_open[par], 0));
+        if ((rc = prove_heavy(ctx, c, batch_view(bd, c, B0), B - B0, out_dev + (size_t)B0 * (BBP_R1CS_PROOF_BYTES + 32 * (size_t)m), ctx->main2, 1)))
+            return rc;
+        BBP_HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->main2));
+        BBP_HIP_TRY(ctx, hipStreamWaitEvent(main_s, ctx->ev_join, 0));
+    }
+    BBP_HIP_TRY(ctx, hipEventRecord(ctx->ev_done[par], main_s));
+    ctx->ev_done_valid[par] = true;
+    ctx->last_par = par;
+    return BBP_OK;
+}
+
+// pointers of `bd` advanced to proof `first` (every array is [proof][stride])
+static BatchDev batch_view(const BatchDev& bd, const CircuitDev& c, u32 first) {
+    BatchDev v = bd;
+    const size_t f = first, n1 = c.n_mul, m = c.m;
+    v.cst += f * c.n_cst; v.v += f * m; v.vb += f * m; v.ai1 += f * (1 + 2 * n1); v.ao1 += f * (1 + n1); v.s1 += f * (1 + 2 * n1);
+    v.tr += f; v.rng += f; v.misc += f * MS_COUNT; v.zpow += f * ((size_t)c.n_cons + 1); v.ypow += f * 2049; v.yipow += f * 2048;
+    v.wl += f * 2048; v.wr += f * 2048; v.wo += f * 2048; v.wv += f * m; v.l1 += f * n1; v.r0 += f * n1; v.r1 += f * n1; v.r3 += f * n1;
+    v.a += f * 2048; v.b += f * 2048; v.g += f * 2048; v.h += f * 2048; v.lr += f * 2 * 2049; v.pts += f * (m + 8); v.lrpts += f * 2;
+    v.enc += f * (m + 8 + 22) * 8; v.entropy += f * (32 * m + 32);
+    return v;
+}
+
+// everything after the opening stage for `B` proofs of the view `bd`, on stream `s`, with MSM scratch slot `slot`
+static int32_t prove_heavy(bbp_ctx* ctx, const CircuitDev& c, const BatchDev& bd, u32 B, u8* out_dev, hipStream_t s, int slot) {
+    int32_t rc;
+    const u32 m = c.m, n1 = c.n_mul, encw = (m + 8 + 22) * 8;
+    DevBuf& ptsbuf = slot ? ctx->pts2 : ctx->pts;
     // A_I1, A_O1, S1 -> pts[m + 0..2] (strided output: launch per commitment with an output view)
-    if ((rc = dev_reserve(ctx, ctx->pts, sizeof(ge) * (size_t)B * 3))) return rc;
-    ge* tmp = static_cast<ge*>(ctx->pts.p);
-    if ((rc = msm_launch(ctx, B, 1 + 2 * n1, (const u32*)bd.ai1, c.idx_ai, tmp, s))) return rc;
-    if ((rc = msm_launch(ctx, B, 1 + n1, (const u32*)bd.ao1, c.idx_ao, tmp + B, s))) return rc;
-    if ((rc = msm_launch(ctx, B, 1 + 2 * n1, (const u32*)bd.s1, c.idx_ai, tmp + 2 * (size_t)B, s))) return rc;
+    if ((rc = dev_reserve(ctx, ptsbuf, sizeof(ge) * (size_t)B * 3))) return rc;
+    ge* tmp = static_cast<ge*>(ptsbuf.p);
+    if ((rc = msm_launch(ctx, B, 1 + 2 * n1, (const u32*)bd.ai1, c.idx_ai, tmp, s, 1, slot))) return rc;
+    if ((rc = msm_launch(ctx, B, 1 + n1, (const u32*)bd.ao1, c.idx_ao, tmp + B, s, 1, slot))) return rc;
+    if ((rc = msm_launch(ctx, B, 1 + 2 * n1, (const u32*)bd.s1, c.idx_ai, tmp + 2 * (size_t)B, s, 1, slot))) return rc;
     for (u32 k = 0; k < 3; k++)
         LAUNCH(ctx, TAG_ENCODE, k_encode_strided, cdiv(B, 64), 64, s, B, 1u, tmp + (size_t)k * B, 1u, bd.enc, encw, 8 * (m + k));
     LAUNCH(ctx, TAG_TRANSCRIPT, k_tr_yz, cdiv(B, 64), 64, s, B, m, bd.enc, bd.tr, bd.misc);
@@ -790,14 +829,11 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
            bd.a, bd.b, bd.g, bd.h);
     for (u32 r = 1; r <= 11; r++) {
         LAUNCH(ctx, TAG_IPA_SCALARS, k_ipa_round, B, IPA_BLK, s, r, m, bd.enc, bd.tr, bd.misc, bd.a, bd.b, bd.g, bd.h, bd.lr);
-        if ((rc = msm_launch(ctx, 2 * B, 2049, (const u32*)bd.lr, c.idx_ipa + (size_t)(r - 1) * 2 * 2049, bd.lrpts, s, 2))) return rc;
+        if ((rc = msm_launch(ctx, 2 * B, 2049, (const u32*)bd.lr, c.idx_ipa + (size_t)(r - 1) * 2 * 2049, bd.lrpts, s, 2, slot))) return rc;
         LAUNCH(ctx, TAG_ENCODE, k_encode_strided, cdiv(2 * B, 64), 64, s, 2 * B, 2u, bd.lrpts, 2u, bd.enc, encw, 8 * (m + 8 + 2 * (r - 1)));
     }
     LAUNCH(ctx, TAG_TRANSCRIPT, k_ipa_final, cdiv(B, 64), 64, s, B, m, bd.enc, bd.tr, bd.misc, bd.a, bd.b);
     LAUNCH(ctx, TAG_TRANSCRIPT, k_assemble, cdiv(B, 64), 64, s, B, m, bd.enc, bd.misc, out_dev);
-    BBP_HIP_TRY(ctx, hipEventRecord(ctx->ev_done[par], s));
-    ctx->ev_done_valid[par] = true;
-    ctx->last_par = par;
     return BBP_OK;
 }
 

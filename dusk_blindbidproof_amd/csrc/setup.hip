@@ -91,6 +91,8 @@ extern "C" int32_t bbp_init(int32_t device, bbp_ctx** out) {
     }
     BBP_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     BBP_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+    BBP_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->main2, hipStreamNonBlocking));
+    BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     for (int i = 0; i < 2; i++) {
         BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_in[i], hipEventDisableTiming));
         BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_open[i], hipEventDisableTiming));
@@ -135,7 +137,7 @@ extern "C" void bbp_free(bbp_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    void* ptrs[] = {ctx->gens, ctx->wtable, ctx->comb, ctx->mimc_c, ctx->scal.p, ctx->idx.p, ctx->sorted.p, ctx->pts.p, ctx->enc.p, ctx->misc.p, ctx->batch.p, ctx->io_in.p, ctx->io_out.p, ctx->io_ent.p, ctx->raw.p, ctx->batch1.p};
+    void* ptrs[] = {ctx->gens, ctx->wtable, ctx->comb, ctx->mimc_c, ctx->scal.p, ctx->idx.p, ctx->sorted.p, ctx->pts.p, ctx->enc.p, ctx->misc.p, ctx->batch.p, ctx->io_in.p, ctx->io_out.p, ctx->io_ent.p, ctx->raw.p, ctx->batch1.p, ctx->sorted2.p, ctx->pts2.p};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int i = 0; i < 2; i++) {
@@ -143,7 +145,9 @@ extern "C" void bbp_free(bbp_ctx* ctx) {
         if (ctx->ev_open[i]) (void)hipEventDestroy(ctx->ev_open[i]);
         if (ctx->ev_done[i]) (void)hipEventDestroy(ctx->ev_done[i]);
     }
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
+    if (ctx->main2) (void)hipStreamDestroy(ctx->main2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
