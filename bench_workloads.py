@@ -158,6 +158,10 @@ class ProveWorkload(_Base):
         # the engine's k_msm launches per prove step: 3 commitment launches + 11 IPA launches (2 MSMs per proof each)
         self.alg_bytes_per_step = batch * ((commit_terms + ipa_terms) * 160 + 32 * (3 + 22))
         self.dominant_launches_per_step = 3 + 11
+        if batch == 1024 and items == 8:
+            # rocprofv3 PMC passes on this exact configuration (profiles/r01_rocprofv3_pmc_hbm.csv): per k_msm launch
+            # FETCH_SIZE 2 616 069 KiB (x2: gfx950 reports half of wide reads, MI355X_MICROARCH.md HBM) + WRITE_SIZE 1 952 272 KiB
+            self.measured_traffic_bytes = (2 * 2616069 + 1952272) * 1024
         self.config = {"workload": "configs[2]: batch of %d full blind-bid R1CS proves (N=%d, 1466 multipliers, 11 IPA rounds)" % (batch, items),
                        "batch_per_gpu": batch, "bid_list_len": items, "msm_window_bits": 11, "parallelism": "batch-sharded",
                        "msm_terms_per_proof": commit_terms + ipa_terms}
