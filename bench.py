@@ -85,11 +85,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # rehearsal knobs (one-GPU box): BBP_BENCH_BACKEND=gloo BBP_BENCH_DEVICE=0 run N ranks against a single card
+    backend = os.environ.get("BBP_BENCH_BACKEND", "nccl")
+    dev_index = int(os.environ.get("BBP_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
+    red_dev = device if backend == "nccl" else torch.device("cpu")
 
     import __graft_entry__ as ge
     if rank == 0:
@@ -100,7 +107,7 @@ def main():
     import dusk_blindbidproof_amd as bbp
     from bench_workloads import make_workload, MsmWorkload, VerifyWorkload
 
-    ctx = bbp.Context(local_rank)
+    ctx = bbp.Context(dev_index)
     wl = make_workload(args.workload, ctx, bbp, torch, device, args.batch, args.items, seed=1 + rank)
     stream = torch.cuda.current_stream().cuda_stream
     for _ in range(args.warmup):
@@ -109,7 +116,7 @@ def main():
     wl.check()  # parity of the warmed-up output against the oracle on a sample (not timed)
 
     dt, timings = timed(wl, ctx, torch, dist, world, args.steps, stream)
-    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+    tmax = torch.tensor([dt], device=red_dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         wl.gather(dist, rank, world)  # the path's one collective: proof records / flags to rank 0
@@ -124,7 +131,7 @@ def main():
             torch.cuda.synchronize()
             w2.check()
             d2, t2 = timed(w2, ctx, torch, dist, world, 3, stream)
-            t2max = torch.tensor([d2], device=device, dtype=torch.float64)
+            t2max = torch.tensor([d2], device=red_dev, dtype=torch.float64)
             if world > 1:
                 dist.all_reduce(t2max, op=dist.ReduceOp.MAX)
             d2 = float(t2max.item())

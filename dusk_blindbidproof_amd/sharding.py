@@ -28,6 +28,8 @@ def gather_records(dist, local, stride, total, rank, world):
     buf[:local.numel()] = local
     if world == 1:
         return buf[:total * stride]
+    if dist.get_backend() != "nccl":
+        buf = buf.cpu()  # gloo: host tensors
     outs = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
     dist.gather(buf, outs, dst=0)
     if rank != 0:
