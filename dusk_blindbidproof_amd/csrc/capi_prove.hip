@@ -7,6 +7,7 @@
 namespace bbp {
 int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* ent_dev, u8* out_dev, hipStream_t s);
 int32_t verify_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* ent_dev, int32_t* status_dev, hipStream_t s);
+int32_t verify_batch_dev_ex(bbp_ctx* ctx, u32 B, u32 N, u32 rec_ver, const u8* in_dev, const u8* ent_dev, int32_t* status_dev, hipStream_t s);
 int32_t debug_read_misc(bbp_ctx* ctx, u32 B, u32 N, u32 proof, uint8_t* out);
 
 // native (non-circuit) image of the gadget wiring: what the reference's Go caller computes before Proof::prove
@@ -179,13 +180,11 @@ extern "C" int32_t bbp_prove(bbp_ctx* ctx, const uint8_t scalars7[7 * 32], const
     return BBP_OK;
 }
 
-extern "C" int32_t bbp_verify_batch(bbp_ctx* ctx, uint32_t B, uint32_t N, const uint8_t* in, int32_t* status) {
-    if (!ctx || !in || !status) return BBP_ERR_BAD_ARG;
-    int32_t rc = check_n(ctx, N);
-    if (rc) return rc;
-    if (B == 0) return BBP_OK;
+// rec_ver 0: compact 1121-byte proofs; 1: the 2-phase 1217-byte R1CSProof layout (both parse in the reference)
+static int32_t verify_batch_host(bbp_ctx* ctx, uint32_t B, uint32_t N, uint32_t rec_ver, const uint8_t* in, int32_t* status) {
+    int32_t rc;
     BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t stride = (size_t)bbp_proof_record_size(N) + 96 + (size_t)N * 32;
+    const size_t stride = (size_t)(rec_ver ? 1217u : 1121u) + 32 * (4 + (size_t)N) + 96 + (size_t)N * 32;
     std::vector<uint8_t> ent((size_t)B * 32);
     if (!os_random(ent.data(), ent.size())) {  // Verifier::verify mixes thread_rng into its TranscriptRng (A.7)
         ctx->err = "cannot read /dev/urandom";
@@ -197,10 +196,19 @@ extern "C" int32_t bbp_verify_batch(bbp_ctx* ctx, uint32_t B, uint32_t N, const 
     BBP_HIP_TRY(ctx, hipMemcpyAsync(ctx->io_in.p, in, stride * B, hipMemcpyHostToDevice, ctx->stream));
     BBP_HIP_TRY(ctx, hipMemcpyAsync(ctx->io_ent.p, ent.data(), ent.size(), hipMemcpyHostToDevice, ctx->stream));
     BBP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if ((rc = verify_batch_dev(ctx, B, N, (const u8*)ctx->io_in.p, (const u8*)ctx->io_ent.p, (int32_t*)ctx->io_out.p, ctx->stream))) return rc;
+    if ((rc = verify_batch_dev_ex(ctx, B, N, rec_ver, (const u8*)ctx->io_in.p, (const u8*)ctx->io_ent.p, (int32_t*)ctx->io_out.p, ctx->stream)))
+        return rc;
     BBP_HIP_TRY(ctx, hipMemcpyAsync(status, ctx->io_out.p, 4 * (size_t)B, hipMemcpyDeviceToHost, ctx->stream));
     BBP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return BBP_OK;
+}
+
+extern "C" int32_t bbp_verify_batch(bbp_ctx* ctx, uint32_t B, uint32_t N, const uint8_t* in, int32_t* status) {
+    if (!ctx || !in || !status) return BBP_ERR_BAD_ARG;
+    int32_t rc = check_n(ctx, N);
+    if (rc) return rc;
+    if (B == 0) return BBP_OK;
+    return verify_batch_host(ctx, B, N, 0, in, status);
 }
 
 extern "C" int32_t bbp_verify_batch_dev(bbp_ctx* ctx, uint32_t B, uint32_t N, const void* in_dev, const void* entropy_dev,
@@ -220,22 +228,38 @@ extern "C" int32_t bbp_verify(bbp_ctx* ctx, const uint8_t* record, uint32_t reco
     int32_t rc = check_n(ctx, N);
     if (rc) return rc;
     if (!pub_list) return BBP_ERR_BAD_ARG;
-    const uint32_t want = bbp_proof_record_size(N);
-    if (record_len != want) {
-        // R1CSProof::from_bytes: only the 1-phase compact layout (1121 bytes) can belong to this circuit; the 2-phase
-        // layout (1217 bytes) parses in the reference but can never verify for a circuit without randomized constraints
-        // unless A_I2 = A_O2 = S2 = identity, which to_bytes would have emitted in the compact form.
-        ctx->err = "record length does not match R1CSProof(1121) || 32*(4+N)";
-        return BBP_ERR_FORMAT;
-    }
-    std::vector<uint8_t> in((size_t)want + 96 + (size_t)N * 32);
-    memcpy(&in[0], record, want);
-    memcpy(&in[want], score, 32);
-    memcpy(&in[want + 32], z_img, 32);
-    memcpy(&in[want + 64], seed, 32);
-    memcpy(&in[want + 96], pub_list, (size_t)N * 32);
+    // Structural parse exactly as R1CSProof::from_bytes / InnerProductProof::from_bytes order their checks:
+    // a record of any length is either a FormatError, or well formed with a wrong IPA depth (-> VerificationError from
+    // verification_scalars, n != 2^lg_n), or one of the two layouts the device kernels take.
+    const uint32_t tail = 32u * (4u + N);
+    if (record_len < tail + 1u) return BBP_ERR_FORMAT;
+    const uint32_t plen = record_len - tail;
+    const uint8_t ver = record[0];
+    if (ver != 0 && ver != 1) return BBP_ERR_FORMAT;
+    if ((plen - 1u) % 32u != 0) return BBP_ERR_FORMAT;
+    const uint32_t nel = (plen - 1u) / 32u, npts = ver == 0 ? 3u : 6u;
+    if (nel < npts + 5u + 3u + 2u) return BBP_ERR_FORMAT;
+    auto canonical = [&](uint32_t el) {
+        u32 w[8];
+        memcpy(w, record + 1 + 32 * (size_t)el, 32);
+        return sc_is_canonical(w);
+    };
+    for (uint32_t k = 0; k < 3; k++)
+        if (!canonical(npts + 5u + k)) return BBP_ERR_FORMAT;  // t_x, t_x_blinding, e_blinding
+    const uint32_t ipp_el = nel - npts - 8u;
+    if (ipp_el < 2u || (ipp_el - 2u) % 2u != 0) return BBP_ERR_FORMAT;
+    const uint32_t lg_n = (ipp_el - 2u) / 2u;
+    if (lg_n >= 32u) return BBP_ERR_FORMAT;
+    if (!canonical(nel - 2u) || !canonical(nel - 1u)) return BBP_ERR_FORMAT;  // a, b
+    if (lg_n != 11u) return BBP_ERR_VERIFY;  // padded_n = 2048 != 2^lg_n
+    std::vector<uint8_t> in((size_t)record_len + 96 + (size_t)N * 32);
+    memcpy(&in[0], record, record_len);
+    memcpy(&in[record_len], score, 32);
+    memcpy(&in[record_len + 32], z_img, 32);
+    memcpy(&in[record_len + 64], seed, 32);
+    memcpy(&in[record_len + 96], pub_list, (size_t)N * 32);
     int32_t st = BBP_ERR_DEVICE;
-    rc = bbp_verify_batch(ctx, 1, N, in.data(), &st);
+    rc = verify_batch_host(ctx, 1, N, ver, in.data(), &st);
     if (rc) return rc;
     return st;
 }

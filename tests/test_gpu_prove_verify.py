@@ -154,3 +154,76 @@ def test_max_list_length(ctx, oc, bbp):
     assert oc.verify(out, *vins[0]) == 0
     rc, crec = oc.prove(ins[0][:224], ins[0][224:224 + 32 * 202], 0, ents[0])
     assert rc == 0 and crec == out
+
+
+def test_record_layout_variants_match_reference_parse_rules(ctx, oc, golden):
+    """R1CSProof::from_bytes accepts the compact (0x00) and the 2-phase (0x01) layouts; a well-formed proof of the wrong IPA depth
+    is a VerificationError, structural damage a FormatError -- same classification on the device, the C oracle and the Python oracle."""
+    from oracle.ref_py import blindbid as pbb, r1cs as pr1cs
+    c = golden("proofs_full.json")["full"][1]
+    rec = bytes.fromhex(c["record"])
+    args = (bytes.fromhex(c["q"]), bytes.fromhex(c["z_img"]), bytes.fromhex(c["seed"]), _pub(c))
+    plen = c["proof_len"]
+    two_phase = b"\x01" + rec[1:97] + bytes(96) + rec[97:]
+    assert ctx.verify(two_phase, *args) == 0 and oc.verify(two_phase, *args) == 0
+    f = lambda k: int.from_bytes(bytes.fromhex(c[k]), "little")
+    pub_int = [int.from_bytes(bytes.fromhex(p), "little") for p in c["pub_list"]]
+    assert pbb.verify(pbb.Proof.from_record(two_phase, c["N"]), f("q"), f("z_img"), f("seed"), pub_int)
+    forged = b"\x01" + rec[1:97] + rec[1:97] + rec[97:]            # non-identity phase-2 points
+    assert ctx.verify(forged, *args) == 1 and oc.verify(forged, *args) == 1
+    shallow = rec[:1 + 32 * 11] + rec[1 + 32 * 11 + 64:]              # drop (L_1, R_1): lg_n = 10, still well formed
+    assert ctx.verify(shallow, *args) == 1 and oc.verify(shallow, *args) == 1
+    with pytest.raises(pr1cs.VerificationError):
+        pbb.verify(pbb.Proof.from_record(shallow, c["N"]), f("q"), f("z_img"), f("seed"), pub_int)
+    odd = rec[:plen - 32] + rec[plen:]                                 # ipp with an odd element count
+    assert ctx.verify(odd, *args) == 3 and oc.verify(odd, *args) == 3
+    assert ctx.verify(rec[:-1], *args) == 3 and ctx.verify(rec[1:], *args) == 3
+    assert ctx.verify(rec[plen - 1:], *args) == 3                      # far too short
+    nc_b = bytearray(rec)
+    nc_b[plen - 32:plen] = b"\xff" * 32                                # non-canonical ipp.b
+    assert ctx.verify(bytes(nc_b), *args) == 3 and oc.verify(bytes(nc_b), *args) == 3
+
+
+@pytest.mark.parametrize("B,N", [(1, 8), (127, 2), (129, 8), (64, 5)])
+def test_batch_geometries_and_buffer_regrowth(ctx, oc, bbp, B, N):
+    """Single-half (< 128) and uneven two-half batches, changing B and N between calls on one context."""
+    ins, ents, vins = _synth_batch(ctx, B, N, seed=1000 + B)
+    out, st = ctx.prove_batch(B, N, b"".join(ins), b"".join(ents))
+    assert st == [0] * B
+    rs_ = bbp.record_size(N)
+    vin = b"".join(out[i * rs_:(i + 1) * rs_] + v[0] + v[1] + v[2] + v[3] for i, v in enumerate(vins))
+    assert ctx.verify_batch(B, N, vin) == [0] * B
+    for i in sorted({0, B // 2 - 1 if B > 1 else 0, B // 2, B - 1}):     # the seams of the two half-batches
+        rc, exp = oc.prove(ins[i][:224], ins[i][224:224 + 32 * N], int.from_bytes(ins[i][-8:], "little"), ents[i])
+        assert rc == 0 and out[i * rs_:(i + 1) * rs_] == exp, i
+    # back-to-back calls reuse the alternate pipeline buffer: results must not depend on call parity
+    out2, _ = ctx.prove_batch(B, N, b"".join(ins), b"".join(ents))
+    assert out2 == out
+
+
+def test_batch_status_per_item(ctx, bbp):
+    ins, ents, _ = _synth_batch(ctx, 4, 3, seed=77)
+    bad_toggle = bytearray(ins[1])
+    bad_toggle[-8:] = (3).to_bytes(8, "little")                          # toggle == N
+    bad_scalar = bytearray(ins[2])
+    bad_scalar[32:64] = b"\xff" * 32                                      # non-canonical k
+    out, st = ctx.prove_batch(4, 3, ins[0] + bytes(bad_toggle) + bytes(bad_scalar) + ins[3], b"".join(ents))
+    assert st == [0, 4, 3, 0]
+    rs_ = bbp.record_size(3)
+    assert out[rs_:3 * rs_] == bytes(2 * rs_) and out[:rs_] != bytes(rs_)
+
+
+def test_verify_large_batch_with_corruptions(ctx, bbp):
+    """Config-4 shaped check at one-GPU scale: 4096 verifications = 64 distinct proofs tiled, ~1 % corrupted at known indices."""
+    N, distinct, B = 8, 64, 4096
+    ins, ents, vins = _synth_batch(ctx, distinct, N, seed=4242)
+    out, st = ctx.prove_batch(distinct, N, b"".join(ins), b"".join(ents))
+    assert st == [0] * distinct
+    rs_ = bbp.record_size(N)
+    rows = [bytearray(out[(i % distinct) * rs_:(i % distinct + 1) * rs_] + b"".join(vins[i % distinct])) for i in range(B)]
+    bad = sorted({(i * 101 + 7) % B for i in range(41)})
+    for i in bad:
+        rows[i][1 + (i * 37) % 1100] ^= 1 << (i % 8)
+    got = ctx.verify_batch(B, N, b"".join(bytes(r) for r in rows))
+    assert [i for i, s in enumerate(got) if s != 0] == bad
+    assert all(got[i] in (1, 3) for i in bad)
