@@ -54,17 +54,24 @@ def timed(wl, ctx, torch, dist, world, steps, stream):
     return dt, timings
 
 
-def roofline(wl, timings, steps):
+def roofline(wl, timings, steps, alu_peak=None):
     dom = [us for tag, us in timings if tag == wl.dominant_tag]
     avg_us = sum(dom) / max(len(dom), 1)
     # algorithmic bytes of the step's dominant-kernel work, spread over the launches that were actually observed
     # (the engine may cut a batch into half-batches on two streams, doubling the launch count)
     alg_per_launch = wl.alg_bytes_per_step * steps / max(len(dom), 1)
     achieved = alg_per_launch / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
-    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": wl.measured_traffic_bytes, "kernel": wl.dominant_kernel, "avg_launch_us": avg_us, "launches": len(dom),
-            "alg_bytes_per_launch": alg_per_launch,
-            "note": "modular-integer path: the binding roofline is 32-bit integer multiply issue, not HBM (DESIGN.md section 5)"}
+    out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+           "traffic": wl.measured_traffic_bytes, "kernel": wl.dominant_kernel, "avg_launch_us": avg_us, "launches": len(dom),
+           "alg_bytes_per_launch": alg_per_launch,
+           "note": "modular-integer path: the binding roofline is 32-bit integer multiply issue, not HBM (DESIGN.md section 5)"}
+    if alu_peak:
+        # secondary, honest roofline (SURVEY.md 7 hard part 2): table-row additions per second against the register-resident
+        # mixed-addition rate measured live by bbp_ubench (no memory traffic).  One 160-byte term = 23 non-zero 11-bit digits.
+        adds = alg_per_launch / 160.0 * 23.0 / (avg_us * 1e-6) if avg_us > 0 else 0.0
+        out["alu"] = {"bound": "v_mad_i64_i32 issue", "achieved": adds, "peak": alu_peak, "unit": "point additions/s",
+                      "frac": adds / alu_peak}
+    return out
 
 
 def main():
@@ -115,6 +122,7 @@ def main():
     torch.cuda.synchronize()
     wl.check()  # parity of the warmed-up output against the oracle on a sample (not timed)
 
+    alu_peak = max(ctx.ubench(3, 8192, 2000) for _ in range(2))  # register-resident ge_madd chains: the integer-ALU ceiling
     dt, timings = timed(wl, ctx, torch, dist, world, args.steps, stream)
     tmax = torch.tensor([dt], device=red_dev, dtype=torch.float64)
     if world > 1:
@@ -136,7 +144,7 @@ def main():
                 dist.all_reduce(t2max, op=dist.ReduceOp.MAX)
             d2 = float(t2max.item())
             also[name] = {"metric": w2.metric, "value": w2.units_per_step * 3 * world / d2, "unit": w2.unit, "steps": 3,
-                          "ms_per_step": d2 / 3 * 1e3, "config": w2.config, "roofline": roofline(w2, t2, 3)}
+                          "ms_per_step": d2 / 3 * 1e3, "config": w2.config, "roofline": roofline(w2, t2, 3, alu_peak)}
             if rank == 0 and world == 1 and not args.no_cpu_baseline and name == "verify":
                 also[name]["cpu_baseline"] = w2.cpu_baseline()
             del w2
@@ -147,7 +155,7 @@ def main():
             "metric": wl.metric, "value": units / dt, "unit": wl.unit, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic", "config": wl.config,
-            "roofline": roofline(wl, timings, args.steps),
+            "roofline": roofline(wl, timings, args.steps, alu_peak),
         }
         out.update(wl.extra_report(timings))
         if also:
