@@ -33,8 +33,10 @@ struct bbp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;            // opening stage of the prover pipeline (prover.hip)
-    hipStream_t main2 = nullptr;           // second half-batch of the heavy stage
-    hipEvent_t ev_join = nullptr;
+    static constexpr int MAX_SLICES = 4;   // heavy-stage slices of one batch, one stream each (slice 0 = caller's stream)
+    hipStream_t lane[MAX_SLICES] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_join[MAX_SLICES] = {nullptr, nullptr, nullptr, nullptr};
+    int slices = 2;
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_open[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     bool ev_done_valid[2] = {false, false}, ev_open_valid[2] = {false, false};
     uint32_t seq = 0;
@@ -48,7 +50,8 @@ struct bbp_ctx {
     uint8_t gens_enc_host_valid = 0;
     std::vector<uint8_t> mimc_host;    // 90 * 32
     // grow-only scratch
-    bbp::DevBuf scal, idx, sorted, sorted2, pts, pts2, enc, misc, batch, batch1, io_in, io_out, io_ent, raw;
+    bbp::DevBuf scal, idx, sorted, pts, enc, misc, batch, batch1, io_in, io_out, io_ent, raw;
+    bbp::DevBuf slice_sorted[MAX_SLICES], slice_pts[MAX_SLICES];  // per-slice MSM scratch (slice 0 uses sorted / pts)
     std::map<uint32_t, void*> circuits;  // N -> CircuitDev* (compiled blind-bid circuit tables on the device)
     std::vector<float> timings;
     // optional per-kernel HIP-event timing (bbp_set_profiling): (tag, start, stop) on the launch stream

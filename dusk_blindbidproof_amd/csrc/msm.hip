@@ -277,7 +277,7 @@ int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* sc
         ctx->err = "msm_launch: n_terms out of range";
         return BBP_ERR_BAD_ARG;
     }
-    DevBuf& scratch = scratch_slot ? ctx->sorted2 : ctx->sorted;  // one scratch area per concurrently running stream
+    DevBuf& scratch = scratch_slot ? ctx->slice_sorted[scratch_slot] : ctx->sorted;  // one scratch area per concurrently running stream
     int32_t rc = dev_reserve(ctx, scratch, msm_scratch_bytes(n_msm, n_terms));
     if (rc) return rc;
     ge* bsum = reinterpret_cast<ge*>(static_cast<u8*>(scratch.p) + msm_sorted_bytes(n_msm, n_terms));

@@ -767,19 +767,20 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
         BBP_HIP_TRY(ctx, hipEventRecord(ctx->ev_open[par], s));
         ctx->ev_open_valid[par] = true;
     }
-    // HEAVY stage.  The batch is cut into two halves that run the same kernel sequence on two streams (the caller's and
-    // the context's second main stream): while one half sits in a latency-bound step (the per-round transcript + scalar
+    // HEAVY stage.  The batch is cut into slices (default 2, BBP_SLICES) that run the same kernel sequence on separate
+    // streams (slice 0 on the caller's): while one slice sits in a latency-bound step (the per-round transcript + scalar
     // inversion in k_ipa_round, the small encode / commit kernels) the other half's MSM keeps the CUs busy.
-    const u32 halves = B >= 128 ? 2u : 1u;
-    const u32 B0 = halves == 2 ? B / 2 : B;
-    BBP_HIP_TRY(ctx, hipStreamWaitEvent(main_s, ctx->ev_open[par], 0));
-    if ((rc = prove_heavy(ctx, c, batch_view(bd, c, 0), B0, out_dev, main_s, 0))) return rc;
-    if (halves == 2) {
-        BBP_HIP_TRY(ctx, hipStreamWaitEvent(ctx->main2, ctx->ev_open[par], 0));
-        if ((rc = prove_heavy(ctx, c, batch_view(bd, c, B0), B - B0, out_dev + (size_t)B0 * (BBP_R1CS_PROOF_BYTES + 32 * (size_t)m), ctx->main2, 1)))
-            return rc;
-        BBP_HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->main2));
-        BBP_HIP_TRY(ctx, hipStreamWaitEvent(main_s, ctx->ev_join, 0));
+    const u32 slices = B >= 64u * (u32)ctx->slices ? (u32)ctx->slices : (B >= 128 ? 2u : 1u);
+    const size_t rec = BBP_R1CS_PROOF_BYTES + 32 * (size_t)m;
+    for (u32 i = 0; i < slices; i++) {
+        const u32 first = (u32)(((u64)B * i) / slices), last = (u32)(((u64)B * (i + 1)) / slices);
+        hipStream_t ls = i == 0 ? main_s : ctx->lane[i];
+        BBP_HIP_TRY(ctx, hipStreamWaitEvent(ls, ctx->ev_open[par], 0));
+        if ((rc = prove_heavy(ctx, c, batch_view(bd, c, first), last - first, out_dev + rec * first, ls, (int)i))) return rc;
+        if (i) {
+            BBP_HIP_TRY(ctx, hipEventRecord(ctx->ev_join[i], ls));
+            BBP_HIP_TRY(ctx, hipStreamWaitEvent(main_s, ctx->ev_join[i], 0));
+        }
     }
     BBP_HIP_TRY(ctx, hipEventRecord(ctx->ev_done[par], main_s));
     ctx->ev_done_valid[par] = true;
@@ -803,7 +804,7 @@ static BatchDev batch_view(const BatchDev& bd, const CircuitDev& c, u32 first) {
 static int32_t prove_heavy(bbp_ctx* ctx, const CircuitDev& c, const BatchDev& bd, u32 B, u8* out_dev, hipStream_t s, int slot) {
     int32_t rc;
     const u32 m = c.m, n1 = c.n_mul, encw = (m + 8 + 22) * 8;
-    DevBuf& ptsbuf = slot ? ctx->pts2 : ctx->pts;
+    DevBuf& ptsbuf = slot ? ctx->slice_pts[slot] : ctx->pts;
     // A_I1, A_O1, S1 -> pts[m + 0..2] (strided output: launch per commitment with an output view)
     if ((rc = dev_reserve(ctx, ptsbuf, sizeof(ge) * (size_t)B * 3))) return rc;
     ge* tmp = static_cast<ge*>(ptsbuf.p);

@@ -6,6 +6,7 @@
 // (src/blindbid/mod.rs:7-24).  Hashing (SHA-512 chain, SHAKE256 stream, SHA3-512) is host work; every field /
 // group operation (Elligator maps, doublings, normalisation) runs on the device.
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "context.h"
 #include "hosthash.h"
@@ -91,8 +92,11 @@ extern "C" int32_t bbp_init(int32_t device, bbp_ctx** out) {
     }
     BBP_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     BBP_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
-    BBP_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->main2, hipStreamNonBlocking));
-    BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    for (int i = 1; i < bbp_ctx::MAX_SLICES; i++) {
+        BBP_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->lane[i], hipStreamNonBlocking));
+        BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming));
+    }
+    if (const char* e = getenv("BBP_SLICES")) ctx->slices = atoi(e) < 1 ? 1 : atoi(e) > bbp_ctx::MAX_SLICES ? bbp_ctx::MAX_SLICES : atoi(e);
     for (int i = 0; i < 2; i++) {
         BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_in[i], hipEventDisableTiming));
         BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_open[i], hipEventDisableTiming));
@@ -137,7 +141,7 @@ extern "C" void bbp_free(bbp_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    void* ptrs[] = {ctx->gens, ctx->wtable, ctx->comb, ctx->mimc_c, ctx->scal.p, ctx->idx.p, ctx->sorted.p, ctx->pts.p, ctx->enc.p, ctx->misc.p, ctx->batch.p, ctx->io_in.p, ctx->io_out.p, ctx->io_ent.p, ctx->raw.p, ctx->batch1.p, ctx->sorted2.p, ctx->pts2.p};
+    void* ptrs[] = {ctx->gens, ctx->wtable, ctx->comb, ctx->mimc_c, ctx->scal.p, ctx->idx.p, ctx->sorted.p, ctx->pts.p, ctx->enc.p, ctx->misc.p, ctx->batch.p, ctx->io_in.p, ctx->io_out.p, ctx->io_ent.p, ctx->raw.p, ctx->batch1.p, ctx->slice_sorted[1].p, ctx->slice_sorted[2].p, ctx->slice_sorted[3].p, ctx->slice_pts[1].p, ctx->slice_pts[2].p, ctx->slice_pts[3].p};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int i = 0; i < 2; i++) {
@@ -145,9 +149,11 @@ extern "C" void bbp_free(bbp_ctx* ctx) {
         if (ctx->ev_open[i]) (void)hipEventDestroy(ctx->ev_open[i]);
         if (ctx->ev_done[i]) (void)hipEventDestroy(ctx->ev_done[i]);
     }
-    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    for (int i = 1; i < bbp_ctx::MAX_SLICES; i++) {
+        if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
+        if (ctx->lane[i]) (void)hipStreamDestroy(ctx->lane[i]);
+    }
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
-    if (ctx->main2) (void)hipStreamDestroy(ctx->main2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
