@@ -35,7 +35,7 @@ struct bbp_ctx {
     hipStream_t side = nullptr;            // opening stage of the prover pipeline (prover.hip)
     static constexpr int MAX_SLICES = 4;   // heavy-stage slices of one batch, one stream each (slice 0 = caller's stream)
     hipStream_t lane[MAX_SLICES] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev_join[MAX_SLICES] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_join[MAX_SLICES] = {nullptr, nullptr, nullptr, nullptr}, ev_stagger[MAX_SLICES] = {nullptr, nullptr, nullptr, nullptr};
     int slices = 2;
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_open[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     bool ev_done_valid[2] = {false, false}, ev_open_valid[2] = {false, false};

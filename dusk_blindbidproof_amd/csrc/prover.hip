@@ -487,6 +487,22 @@ __global__ void k_lrvec(u32 B, u32 n1, const sc* __restrict__ l1, const sc* __re
     st_sc(&h[(size_t)p * 2048 + i], sc_mul(ld_sc(&yipow[(size_t)p * 2048 + i]), gv));
 }
 
+// Fiat-Shamir step between IPA rounds: absorb L_j, R_j (j = prev_round), draw u_j, invert it.  One lane per proof.
+__global__ void k_ipa_challenge(u32 B, u32 prev_round, u32 m, const u32* __restrict__ enc, merlin_transcript* __restrict__ tr,
+                                sc* __restrict__ misc) {
+    u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= B) return;
+    merlin_transcript t = tr[p];
+    const u32* e = enc + (size_t)p * enc_stride_words(m) + 8 * (m + 8) + 16 * (prev_round - 1);
+    tr_append_words(t, LBL("L"), e);
+    tr_append_words(t, LBL("R"), e + 8);
+    sc u = tr_challenge_sc(t, LBL("u"));
+    sc* ms = misc + (size_t)p * MS_COUNT;
+    st_sc(&ms[MS_UJ], u);
+    st_sc(&ms[MS_UJI], sc_invert(u));
+    tr[p] = t;
+}
+
 // K6: one inner-product round.  n = half length of THIS round (1024 >> (round-1)).
 //   round > 1: lane 0 first absorbs the previous L, R, draws u, inverts it; everyone folds a, b and updates g, h.
 //   then: c_L, c_R and the scalars of this round's L and R over the ORIGINAL generators.
@@ -500,28 +516,14 @@ __global__ __launch_bounds__(IPA_BLK) void k_ipa_round(u32 round, u32 m, const u
     sc* ms = misc + (size_t)p * MS_COUNT;
     sc *a = a_all + (size_t)p * 2048, *b = b_all + (size_t)p * 2048, *g = g_all + (size_t)p * 2048, *h = h_all + (size_t)p * 2048;
     const u32 n = 1024u >> (round - 1);
+    (void)enc;
+    (void)tr;
+    (void)m;
+    (void)bc;
     if (round > 1) {
-        if (tid == 0) {
-            merlin_transcript t = tr[p];
-            const u32* e = enc + (size_t)p * enc_stride_words(m) + 8 * (m + 8) + 16 * (round - 2);
-            tr_append_words(t, LBL("L"), e);
-            tr_append_words(t, LBL("R"), e + 8);
-            sc u = tr_challenge_sc(t, LBL("u"));
-            sc ui = sc_invert(u);
-            tr[p] = t;
-#pragma unroll
-            for (int w = 0; w < 8; w++) {
-                bc[w] = u.v[w];
-                bc[8 + w] = ui.v[w];
-            }
-        }
-        __syncthreads();
-        sc u, ui;
-#pragma unroll
-        for (int w = 0; w < 8; w++) {
-            u.v[w] = bc[w];
-            ui.v[w] = bc[8 + w];
-        }
+        // u, u^-1 of the previous round were produced by k_ipa_challenge (one lane per proof, its own tiny launch, so that
+        // this 256-lane block is never resident while a single lane hashes and inverts)
+        const sc u = ld_sc(&ms[MS_UJ]), ui = ld_sc(&ms[MS_UJI]);
         const u32 n2 = 2 * n;  // half length of the previous round = current full length
         // fold a, b: a'[i] = a[i] u + u^-1 a[n2+i] ; b'[i] = b[i] u^-1 + u b[n2+i]
         for (u32 i = tid; i < n2; i += IPA_BLK) {
@@ -730,7 +732,8 @@ static merlin_transcript prover_prefix() {
 static inline u32 cdiv(u32 a, u32 b) { return (a + b - 1) / b; }
 
 static BatchDev batch_view(const BatchDev& bd, const CircuitDev& c, u32 first);
-static int32_t prove_heavy(bbp_ctx* ctx, const CircuitDev& c, const BatchDev& bd, u32 B, u8* out_dev, hipStream_t s, int slot);
+static int32_t prove_heavy(bbp_ctx* ctx, const CircuitDev& c, const BatchDev& bd, u32 B, u8* out_dev, hipStream_t s, int slot,
+                           hipEvent_t stagger);
 
 // in_dev: B * (7*32 + N*32 + 8) ; ent_dev: B * (32 m + 32) ; out_dev: B * (1121 + 32 m).  All device pointers.
 int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* ent_dev, u8* out_dev, hipStream_t s) {
@@ -776,7 +779,12 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
         const u32 first = (u32)(((u64)B * i) / slices), last = (u32)(((u64)B * (i + 1)) / slices);
         hipStream_t ls = i == 0 ? main_s : ctx->lane[i];
         BBP_HIP_TRY(ctx, hipStreamWaitEvent(ls, ctx->ev_open[par], 0));
-        if ((rc = prove_heavy(ctx, c, batch_view(bd, c, first), last - first, out_dev + rec * first, ls, (int)i))) return rc;
+        // stagger: slices run the same kernel sequence, so started together their latency-bound steps would coincide; each
+        // slice waits for the previous slice's first MSM, which puts its serial steps under the neighbour's MSMs
+        if (i) BBP_HIP_TRY(ctx, hipStreamWaitEvent(ls, ctx->ev_stagger[i - 1], 0));
+        if ((rc = prove_heavy(ctx, c, batch_view(bd, c, first), last - first, out_dev + rec * first, ls, (int)i,
+                              i + 1 < slices ? ctx->ev_stagger[i] : nullptr)))
+            return rc;
         if (i) {
             BBP_HIP_TRY(ctx, hipEventRecord(ctx->ev_join[i], ls));
             BBP_HIP_TRY(ctx, hipStreamWaitEvent(main_s, ctx->ev_join[i], 0));
@@ -801,7 +809,8 @@ static BatchDev batch_view(const BatchDev& bd, const CircuitDev& c, u32 first) {
 }
 
 // everything after the opening stage for `B` proofs of the view `bd`, on stream `s`, with MSM scratch slot `slot`
-static int32_t prove_heavy(bbp_ctx* ctx, const CircuitDev& c, const BatchDev& bd, u32 B, u8* out_dev, hipStream_t s, int slot) {
+static int32_t prove_heavy(bbp_ctx* ctx, const CircuitDev& c, const BatchDev& bd, u32 B, u8* out_dev, hipStream_t s, int slot,
+                           hipEvent_t stagger) {
     int32_t rc;
     const u32 m = c.m, n1 = c.n_mul, encw = (m + 8 + 22) * 8;
     DevBuf& ptsbuf = slot ? ctx->slice_pts[slot] : ctx->pts;
@@ -809,6 +818,7 @@ static int32_t prove_heavy(bbp_ctx* ctx, const CircuitDev& c, const BatchDev& bd
     if ((rc = dev_reserve(ctx, ptsbuf, sizeof(ge) * (size_t)B * 3))) return rc;
     ge* tmp = static_cast<ge*>(ptsbuf.p);
     if ((rc = msm_launch(ctx, B, 1 + 2 * n1, (const u32*)bd.ai1, c.idx_ai, tmp, s, 1, slot))) return rc;
+    if (stagger) BBP_HIP_TRY(ctx, hipEventRecord(stagger, s));  // the next slice starts one MSM behind this one
     if ((rc = msm_launch(ctx, B, 1 + n1, (const u32*)bd.ao1, c.idx_ao, tmp + B, s, 1, slot))) return rc;
     if ((rc = msm_launch(ctx, B, 1 + 2 * n1, (const u32*)bd.s1, c.idx_ai, tmp + 2 * (size_t)B, s, 1, slot))) return rc;
     for (u32 k = 0; k < 3; k++)
@@ -829,6 +839,7 @@ static int32_t prove_heavy(bbp_ctx* ctx, const CircuitDev& c, const BatchDev& bd
     LAUNCH(ctx, TAG_POLY, k_lrvec, cdiv(B * 2048, 128), 128, s, B, n1, bd.l1, bd.r0, bd.r1, bd.r3, bd.ao1, bd.s1, bd.ypow, bd.yipow, bd.misc,
            bd.a, bd.b, bd.g, bd.h);
     for (u32 r = 1; r <= 11; r++) {
+        if (r > 1) LAUNCH(ctx, TAG_TRANSCRIPT, k_ipa_challenge, cdiv(B, 64), 64, s, B, r - 1, m, bd.enc, bd.tr, bd.misc);
         LAUNCH(ctx, TAG_IPA_SCALARS, k_ipa_round, B, IPA_BLK, s, r, m, bd.enc, bd.tr, bd.misc, bd.a, bd.b, bd.g, bd.h, bd.lr);
         if ((rc = msm_launch(ctx, 2 * B, 2049, (const u32*)bd.lr, c.idx_ipa + (size_t)(r - 1) * 2 * 2049, bd.lrpts, s, 2, slot))) return rc;
         LAUNCH(ctx, TAG_ENCODE, k_encode_strided, cdiv(2 * B, 64), 64, s, 2 * B, 2u, bd.lrpts, 2u, bd.enc, encw, 8 * (m + 8 + 2 * (r - 1)));

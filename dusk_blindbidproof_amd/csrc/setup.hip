@@ -95,6 +95,7 @@ extern "C" int32_t bbp_init(int32_t device, bbp_ctx** out) {
     for (int i = 1; i < bbp_ctx::MAX_SLICES; i++) {
         BBP_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->lane[i], hipStreamNonBlocking));
         BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming));
+        BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_stagger[i - 1], hipEventDisableTiming));
     }
     if (const char* e = getenv("BBP_SLICES")) ctx->slices = atoi(e) < 1 ? 1 : atoi(e) > bbp_ctx::MAX_SLICES ? bbp_ctx::MAX_SLICES : atoi(e);
     for (int i = 0; i < 2; i++) {
@@ -151,6 +152,7 @@ extern "C" void bbp_free(bbp_ctx* ctx) {
     }
     for (int i = 1; i < bbp_ctx::MAX_SLICES; i++) {
         if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
+        if (ctx->ev_stagger[i - 1]) (void)hipEventDestroy(ctx->ev_stagger[i - 1]);
         if (ctx->lane[i]) (void)hipStreamDestroy(ctx->lane[i]);
     }
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
