@@ -45,6 +45,7 @@ extern "C" int32_t bbp_msm_batch_dev(bbp_ctx* ctx, uint32_t B, uint32_t n_terms,
     std::vector<u32> idx;
     int32_t rc = layout_base_indices(layout, n_terms, idx, ctx->err);
     if (rc) return rc;
+    if ((rc = stream_guard_enter(ctx, stream))) return rc;
     rc = dev_reserve(ctx, ctx->idx, idx.size() * 4);
     if (rc) return rc;
     rc = dev_reserve(ctx, ctx->pts, sizeof(ge) * (size_t)B);
@@ -52,7 +53,8 @@ extern "C" int32_t bbp_msm_batch_dev(bbp_ctx* ctx, uint32_t B, uint32_t n_terms,
     BBP_HIP_TRY(ctx, hipMemcpyAsync(ctx->idx.p, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, stream));
     rc = msm_launch(ctx, B, n_terms, (const u32*)scalars_dev, (const u32*)ctx->idx.p, (ge*)ctx->pts.p, stream);
     if (rc) return rc;
-    return encode_launch(ctx, B, (const ge*)ctx->pts.p, (uint8_t*)out32_dev, stream);
+    if ((rc = encode_launch(ctx, B, (const ge*)ctx->pts.p, (uint8_t*)out32_dev, stream))) return rc;
+    return stream_guard_leave(ctx, stream);
 }
 
 extern "C" int32_t bbp_msm_batch(bbp_ctx* ctx, uint32_t B, uint32_t n_terms, const uint8_t* scalars, uint32_t layout,

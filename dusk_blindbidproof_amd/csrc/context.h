@@ -41,6 +41,11 @@ struct bbp_ctx {
     bool ev_done_valid[2] = {false, false}, ev_open_valid[2] = {false, false};
     uint32_t seq = 0;
     int last_par = 0;
+    // calls on one context share scratch buffers: a call issued on a different caller stream than the previous one is ordered
+    // behind it (stream_guard_enter / stream_guard_leave)
+    hipStream_t last_stream = nullptr;
+    hipEvent_t ev_last = nullptr;
+    bool ev_last_valid = false;
     std::string err;
     // resident tables
     bbp::ge* gens = nullptr;           // [BBP_NUM_BASES] extended points: B_blinding, G[2048], H[2048], B
@@ -105,6 +110,17 @@ struct ScopedEvent {  // records start now, stop at scope exit, when profiling i
         if (idx >= 0) (void)hipEventRecord(ctx->events[idx].b, s);
     }
 };
+
+inline int32_t stream_guard_enter(bbp_ctx* ctx, hipStream_t s) {
+    if (ctx->ev_last_valid && ctx->last_stream != s) BBP_HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_last, 0));
+    return BBP_OK;
+}
+inline int32_t stream_guard_leave(bbp_ctx* ctx, hipStream_t s) {
+    BBP_HIP_TRY(ctx, hipEventRecord(ctx->ev_last, s));
+    ctx->ev_last_valid = true;
+    ctx->last_stream = s;
+    return BBP_OK;
+}
 
 // msm.hip
 // base_idx_dev holds n_idx_sets lists of n_terms indices; MSM number i uses list (i % n_idx_sets)

@@ -32,7 +32,10 @@ __device__ __forceinline__ ge lds_get(const u32* stage, int t) {
 }
 
 __device__ __forceinline__ niels_packed load_raw(const niels_packed* __restrict__ tab, u32 entry) {
-    const uint4* p = reinterpret_cast<const uint4*>(tab + (entry & 0x7fffffffu));
+    // the row index is clamped: a corrupted scratch entry must never turn into an out-of-bounds gather (a GPU fault here
+    // takes the whole node down); one v_min_u32 per 2000-instruction iteration
+    const u32 row = min(entry & 0x7fffffffu, (u32)(BBP_NUM_BASES * MSM_W - 1));
+    const uint4* p = reinterpret_cast<const uint4*>(tab + row);
     uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4], q5 = p[5];
     niels_packed r = {{q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w,
                        q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w}};

@@ -746,6 +746,7 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
     // -- so it runs on the context's side stream into the batch buffer of this call's parity, while the caller's stream is
     // still busy with the MSM-heavy stage of the PREVIOUS call (other parity).  Events order: inputs (caller stream) ->
     // opening (side) -> heavy stage (caller stream); a buffer is reused only after its previous heavy stage has finished.
+    if ((rc = stream_guard_enter(ctx, s))) return rc;
     const int par = (int)(ctx->seq++ & 1u);
     BatchDev bd;
     if ((rc = batch_reserve(ctx, B, c, bd, par))) return rc;
@@ -793,7 +794,7 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
     BBP_HIP_TRY(ctx, hipEventRecord(ctx->ev_done[par], main_s));
     ctx->ev_done_valid[par] = true;
     ctx->last_par = par;
-    return BBP_OK;
+    return stream_guard_leave(ctx, main_s);
 }
 
 // pointers of `bd` advanced to proof `first` (every array is [proof][stride])

@@ -227,3 +227,39 @@ def test_verify_large_batch_with_corruptions(ctx, bbp):
     got = ctx.verify_batch(B, N, b"".join(bytes(r) for r in rows))
     assert [i for i, s in enumerate(got) if s != 0] == bad
     assert all(got[i] in (1, 3) for i in bad)
+
+
+def test_calls_from_different_streams_are_serialised(ctx, oc, bbp):
+    """One context shares scratch between calls; calls issued on different caller streams must still be ordered (stream guard).
+    Regression: two chunks in flight on two streams once raced on the MSM scratch and faulted the GPU."""
+    import torch
+    dev = torch.device("cuda", 0)
+    B, N = 160, 4
+    ins, ents, vins = _synth_batch(ctx, B, N, seed=31337)
+    rs_ = bbp.record_size(N)
+    d_in = torch.frombuffer(bytearray(b"".join(ins)), dtype=torch.uint8).to(dev)
+    d_ent = torch.frombuffer(bytearray(b"".join(ents)), dtype=torch.uint8).to(dev)
+    vtail = torch.frombuffer(bytearray(b"".join(b"".join(v) for v in vins)), dtype=torch.uint8).to(dev).view(B, 96 + 32 * N)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    outs, sts = [], []
+    for it in range(6):
+        st = streams[it % 3]
+        with torch.cuda.stream(st):
+            out = torch.zeros(B * rs_, dtype=torch.uint8, device=dev)
+            ctx.prove_batch_dev(B, N, d_in.data_ptr(), d_ent.data_ptr(), out.data_ptr(), st.cuda_stream)
+            vin = torch.empty((B, rs_ + 96 + 32 * N), dtype=torch.uint8, device=dev)
+            vin[:, :rs_] = out.view(B, rs_)
+            vin[:, rs_:] = vtail
+            status = torch.full((B,), -1, dtype=torch.int32, device=dev)
+            ctx.verify_batch_dev(B, N, vin.data_ptr(), torch.zeros(B * 32, dtype=torch.uint8, device=dev).data_ptr(), status.data_ptr(),
+                                 st.cuda_stream)
+            outs.append((out, vin))
+            sts.append(status)
+    torch.cuda.synchronize()
+    ref = bytes(outs[0][0].cpu().numpy().tobytes())
+    rc, exp = oc.prove(ins[B - 1][:224], ins[B - 1][224:224 + 32 * N], int.from_bytes(ins[B - 1][-8:], "little"), ents[B - 1])
+    assert rc == 0 and ref[(B - 1) * rs_:] == exp
+    for (out, _), status in zip(outs, sts):
+        assert bytes(out.cpu().numpy().tobytes()) == ref
+        assert status.cpu().tolist() == [0] * B
