@@ -31,6 +31,12 @@ def bbp(built):
 
 @pytest.fixture(scope="session")
 def ctx(bbp):
+    try:  # tests that also use torch streams need torch's HIP runtime initialised before ours is (bench.py's order)
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     c = bbp.Context(0)  # raises loudly without a gfx950 device: no fallback
     yield c
     c.close()
