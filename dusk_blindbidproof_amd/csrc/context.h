@@ -37,6 +37,7 @@ struct bbp_ctx {
     hipStream_t lane[MAX_SLICES] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_join[MAX_SLICES] = {nullptr, nullptr, nullptr, nullptr}, ev_stagger[MAX_SLICES] = {nullptr, nullptr, nullptr, nullptr};
     int slices = 2;
+    int stagger_mode = 0;  // 0: slices start together, 1: next slice starts after this slice's first MSM, 3: after its third (BBP_STAGGER)
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_open[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     bool ev_done_valid[2] = {false, false}, ev_open_valid[2] = {false, false};
     uint32_t seq = 0;

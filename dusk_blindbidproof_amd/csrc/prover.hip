@@ -782,7 +782,7 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
         BBP_HIP_TRY(ctx, hipStreamWaitEvent(ls, ctx->ev_open[par], 0));
         // stagger: slices run the same kernel sequence, so started together their latency-bound steps would coincide; each
         // slice waits for the previous slice's first MSM, which puts its serial steps under the neighbour's MSMs
-        if (i) BBP_HIP_TRY(ctx, hipStreamWaitEvent(ls, ctx->ev_stagger[i - 1], 0));
+        if (i && ctx->stagger_mode) BBP_HIP_TRY(ctx, hipStreamWaitEvent(ls, ctx->ev_stagger[i - 1], 0));
         if ((rc = prove_heavy(ctx, c, batch_view(bd, c, first), last - first, out_dev + rec * first, ls, (int)i,
                               i + 1 < slices ? ctx->ev_stagger[i] : nullptr)))
             return rc;
@@ -819,9 +819,12 @@ static int32_t prove_heavy(bbp_ctx* ctx, const CircuitDev& c, const BatchDev& bd
     if ((rc = dev_reserve(ctx, ptsbuf, sizeof(ge) * (size_t)B * 3))) return rc;
     ge* tmp = static_cast<ge*>(ptsbuf.p);
     if ((rc = msm_launch(ctx, B, 1 + 2 * n1, (const u32*)bd.ai1, c.idx_ai, tmp, s, 1, slot))) return rc;
-    if (stagger) BBP_HIP_TRY(ctx, hipEventRecord(stagger, s));  // the next slice starts one MSM behind this one
+    if (stagger && ctx->stagger_mode == 1) BBP_HIP_TRY(ctx, hipEventRecord(stagger, s));
     if ((rc = msm_launch(ctx, B, 1 + n1, (const u32*)bd.ao1, c.idx_ao, tmp + B, s, 1, slot))) return rc;
     if ((rc = msm_launch(ctx, B, 1 + 2 * n1, (const u32*)bd.s1, c.idx_ai, tmp + 2 * (size_t)B, s, 1, slot))) return rc;
+    // the next slice starts once this one has issued its three commitment MSMs: its own commitment MSMs then run under this
+    // slice's long MSM-free stretch (encode, transcript, powers, flatten, poly, T commitments, l/r vectors)
+    if (stagger && ctx->stagger_mode == 3) BBP_HIP_TRY(ctx, hipEventRecord(stagger, s));
     for (u32 k = 0; k < 3; k++)
         LAUNCH(ctx, TAG_ENCODE, k_encode_strided, cdiv(B, 64), 64, s, B, 1u, tmp + (size_t)k * B, 1u, bd.enc, encw, 8 * (m + k));
     LAUNCH(ctx, TAG_TRANSCRIPT, k_tr_yz, cdiv(B, 64), 64, s, B, m, bd.enc, bd.tr, bd.misc);
