@@ -53,6 +53,7 @@ struct BatchDev {
     sc* lr;       // [2][2049] scalars of L and R of the current round
     ge* pts;      // [m + 8] V points, then A_I1, A_O1, S1, T_1, T_3, T_4, T_5, T_6
     ge* lrpts;    // [2]
+    ge* fpts;     // [2][FOLD_CLS] explicit folded generators of the IPA tail: F_G then F_H
     u32* enc;     // [(m + 8 + 22) * 8] encodings: V[m], A_I1, A_O1, S1, T1,T3,T4,T5,T6, (L_j, R_j) x 11
     u8* entropy;  // [32 (4+N) + 32]
 };

@@ -20,6 +20,13 @@ constexpr int MSM_K = 1 << (MSM_C - 1);   // 1024 buckets (|digit| = 1..1024)
 constexpr int MSM_T = 128;                // threads per MSM workgroup (2 wavefronts)
 constexpr int MSM_G = MSM_K / MSM_T;      // 8 consecutive buckets per lane
 constexpr int MSM_LOG_G = 3;
+// IPA tail (prover.hip): from round FOLD_ROUND the folded generators are explicit points; they are materialised by a
+// composite-bucket Pippenger pass over an 8-bit-window row table (msm.hip k_fold_generators)
+constexpr int FOLD_ROUND = 7;              // first tail round: vectors of length 32 (halves of 16)
+constexpr int FOLD_CLS = 2048 >> (FOLD_ROUND - 1);  // 32 folded generators per side
+constexpr int FOLD_W = 32;                 // 8-bit windows
+constexpr int FOLD_M = 128;                // |digit| values
+constexpr int FOLD_K = FOLD_CLS * FOLD_M;  // 4096 composite buckets
 constexpr int GE_WORDS = sizeof(ge) / 4;  // 40: a point in registers / LDS / scratch
 
 struct DevBuf {
@@ -37,6 +44,7 @@ struct bbp_ctx {
     hipStream_t lane[MAX_SLICES] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_join[MAX_SLICES] = {nullptr, nullptr, nullptr, nullptr}, ev_stagger[MAX_SLICES] = {nullptr, nullptr, nullptr, nullptr};
     int slices = 2;
+    int tail_round = bbp::FOLD_ROUND;  // first IPA round run on explicit folded generators (BBP_TAIL_ROUND=12 disables)
     int stagger_mode = 0;  // 0: slices start together, 1: next slice starts after this slice's first MSM, 3: after its third (BBP_STAGGER)
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_open[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     bool ev_done_valid[2] = {false, false}, ev_open_valid[2] = {false, false};
@@ -50,6 +58,7 @@ struct bbp_ctx {
     std::string err;
     // resident tables
     bbp::ge* gens = nullptr;           // [BBP_NUM_BASES] extended points: B_blinding, G[2048], H[2048], B
+    bbp::niels_packed* wtable8 = nullptr;  // [BBP_NUM_BASES * FOLD_W] 2^(8 j) * P_i rows for the generator-folding pass
     bbp::niels_packed* wtable = nullptr;   // [BBP_NUM_BASES * MSM_W] affine cached 2^(11 j) * P_i
     bbp::niels_packed* comb = nullptr;     // [2][64][8] radix-16 comb for B and B_blinding (small commits)
     bbp::sc* mimc_c = nullptr;         // [90]
@@ -57,7 +66,7 @@ struct bbp_ctx {
     std::vector<uint8_t> mimc_host;    // 90 * 32
     // grow-only scratch
     bbp::DevBuf scal, idx, sorted, pts, enc, misc, batch, batch1, io_in, io_out, io_ent, raw;
-    bbp::DevBuf slice_sorted[MAX_SLICES], slice_pts[MAX_SLICES];  // per-slice MSM scratch (slice 0 uses sorted / pts)
+    bbp::DevBuf slice_sorted[MAX_SLICES], slice_pts[MAX_SLICES], slice_fold[MAX_SLICES], slice_vtab[MAX_SLICES];  // per-slice MSM scratch (slice 0 uses sorted / pts)
     std::map<uint32_t, void*> circuits;  // N -> CircuitDev* (compiled blind-bid circuit tables on the device)
     std::vector<float> timings;
     // optional per-kernel HIP-event timing (bbp_set_profiling): (tag, start, stop) on the launch stream
@@ -127,6 +136,8 @@ inline int32_t stream_guard_leave(bbp_ctx* ctx, hipStream_t s) {
 // base_idx_dev holds n_idx_sets lists of n_terms indices; MSM number i uses list (i % n_idx_sets)
 int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* scalars_dev, const u32* base_idx_dev,
                    ge* out_points_dev, hipStream_t stream, uint32_t n_idx_sets = 1, int scratch_slot = 0);
+int32_t fold_generators_launch(bbp_ctx* ctx, uint32_t n_proofs, const sc* g_dev, const sc* h_dev, ge* out_dev, hipStream_t stream,
+                               int scratch_slot);
 int32_t encode_launch(bbp_ctx* ctx, uint32_t n, const ge* pts_dev, uint8_t* out32_dev, hipStream_t stream);
 size_t msm_scratch_bytes(uint32_t n_msm, uint32_t n_terms);
 

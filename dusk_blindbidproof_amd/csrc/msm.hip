@@ -42,6 +42,15 @@ __device__ __forceinline__ niels_packed load_raw(const niels_packed* __restrict_
     return r;
 }
 
+__device__ __forceinline__ niels_packed load_raw8(const niels_packed* __restrict__ tab, u32 entry) {
+    const u32 row = min(entry & 0x7fffffffu, (u32)(BBP_NUM_BASES * FOLD_W - 1));
+    const uint4* p = reinterpret_cast<const uint4*>(tab + row);
+    uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4], q5 = p[5];
+    niels_packed r = {{q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w,
+                       q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w}};
+    return r;
+}
+
 // packed row -> limbs; a negative digit uses -(x, y) = (-x, y): swap y+x / y-x and negate 2dxy
 __device__ __forceinline__ ge_niels unpack_niels(const niels_packed& r, u32 neg) {
     ge_niels n;
@@ -254,6 +263,183 @@ __global__ __launch_bounds__(MSM_T) void k_msm(const u32* __restrict__ scalars, 
         __syncthreads();
     }
     if (tid == 0) out[msm] = x;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Materialising folded generators for the tail of the inner-product argument.
+//
+// From round FOLD_ROUND on, the IPA vectors are at most 32 long, and two 2049-term fixed-base MSMs per round cost far more
+// than working with the 32 + 32 explicit folded generators F_G[i] = sum_{k = i mod 32} g[k] G[k] (and F_H likewise).
+// This kernel computes those 32 sums of one side (G or H) of one proof in ONE Pippenger pass with COMPOSITE buckets
+// key = class(k) * 128 + |digit| (8-bit signed digits, 32 windows, row table 2^(8 j) P): same histogram / counting sort /
+// balanced accumulation as k_msm, then a running-sum fold per class (4 lanes of 32 keys each).
+// ---------------------------------------------------------------------------------------------------------------
+template <class F>
+__device__ __forceinline__ void for_each_digit8(const u32 (&s)[8], F&& f) {
+    u32 carry = 0;
+#pragma unroll
+    for (int j = 0; j < FOLD_W; j++) {
+        u32 d = ((s[j >> 2] >> (8 * (j & 3))) & 0xffu) + carry;
+        carry = d > 128u;
+        u32 mag = carry ? 256u - d : d;
+        if (mag) f(j, mag, carry);
+    }  // scalars are < 2^253: byte 31 never carries out
+}
+
+__global__ __launch_bounds__(MSM_T) void k_fold_generators(const sc* __restrict__ g_all, const sc* __restrict__ h_all,
+                                                            const niels_packed* __restrict__ wtable8, u32* __restrict__ sorted_all,
+                                                            ge* __restrict__ bsum_all, ge* __restrict__ psum_all, ge* __restrict__ out) {
+    __shared__ u32 cnt[FOLD_K + 1];
+    __shared__ u32 cursor[FOLD_K + 1];
+    __shared__ u32 part[MSM_T];
+    __shared__ u32 stage[GE_WORDS * MSM_T];
+    const int tid = threadIdx.x;
+    const size_t msm = blockIdx.x;
+    const u32 side = blockIdx.x & 1u;  // 0: G with g[], 1: H with h[]
+    const u32* sbase = reinterpret_cast<const u32*>(side ? h_all : g_all) + (msm >> 1) * (size_t)2048 * 8;
+    const u32 base0 = side ? BBP_BASE_H0 : BBP_BASE_G0;
+    u32* sorted = sorted_all + msm * (size_t)2048 * FOLD_W;
+    constexpr int G2 = FOLD_K / MSM_T;  // 32 keys per lane = a quarter of one class
+
+    for (int k = tid; k <= FOLD_K; k += MSM_T) cnt[k] = 0;
+    __syncthreads();
+    for (u32 i = tid; i < 2048; i += MSM_T) {
+        const uint4* sp = reinterpret_cast<const uint4*>(sbase + (size_t)i * 8);
+        uint4 lo = sp[0], hi = sp[1];
+        const u32 s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        const u32 cls = (i & (FOLD_CLS - 1)) * FOLD_M;
+        for_each_digit8(s, [&](int, u32 mag, u32) { atomicAdd(&cnt[cls + mag], 1u); });
+    }
+    __syncthreads();
+    {
+        u32 local = 0;
+        for (int r = 1; r <= G2; r++) local += cnt[tid * G2 + r];
+        part[tid] = local;
+        __syncthreads();
+        if (tid == 0) {
+            u32 run = 0;
+            for (int t = 0; t < MSM_T; t++) {
+                u32 v = part[t];
+                part[t] = run;
+                run += v;
+            }
+        }
+        __syncthreads();
+        u32 base = part[tid];
+        for (int r = 1; r <= G2; r++) {
+            cursor[tid * G2 + r] = base;
+            base += cnt[tid * G2 + r];
+        }
+    }
+    __syncthreads();
+    for (u32 i = tid; i < 2048; i += MSM_T) {
+        const uint4* sp = reinterpret_cast<const uint4*>(sbase + (size_t)i * 8);
+        uint4 lo = sp[0], hi = sp[1];
+        const u32 s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        const u32 cls = (i & (FOLD_CLS - 1)) * FOLD_M;
+        const u32 tb = (base0 + i) * FOLD_W;
+        for_each_digit8(s, [&](int j, u32 mag, u32 neg) {
+            u32 pos = atomicAdd(&cursor[cls + mag], 1u);
+            sorted[pos] = (tb + (u32)j) | (neg << 31);
+        });
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    const u32 E = cursor[FOLD_K];
+    if (tid == 0) cursor[0] = 0;
+    ge* bsum = bsum_all + msm * (size_t)FOLD_K;
+    ge* psum = psum_all + msm * (size_t)MSM_T;
+    const u32 c0 = (u32)(((u64)tid * E) / MSM_T), c1 = (u32)(((u64)(tid + 1) * E) / MSM_T);
+    __syncthreads();
+    if (c0 < c1) {
+        u32 lo = 1, hi = FOLD_K;
+        while (lo < hi) {
+            u32 mid = (lo + hi) >> 1;
+            if (cursor[mid] > c0) hi = mid; else lo = mid + 1;
+        }
+        u32 k = lo, kend = cursor[k];
+        ge* dest = (cursor[k - 1] < c0) ? &psum[tid] : &bsum[k - 1];
+        ge acc = ge_identity();
+        u32 ent_cur = sorted[c0];
+        u32 ent_nxt = (c0 + 1 < c1) ? sorted[c0 + 1] : 0u;
+        niels_packed raw = load_raw8(wtable8, ent_cur);
+        for (u32 e = c0; e < c1; e++) {
+            if (e == kend) {
+                *dest = acc;
+                acc = ge_identity();
+                do { k++; kend = cursor[k]; } while (kend == e);
+                dest = &bsum[k - 1];
+            }
+            ge_niels cur = unpack_niels(raw, ent_cur >> 31);
+            ent_cur = ent_nxt;
+            if (e + 1 < c1) raw = load_raw8(wtable8, ent_cur);
+            if (e + 2 < c1) ent_nxt = sorted[e + 2];
+            acc = ge_madd(acc, cur);
+        }
+        *dest = acc;
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // per-lane running-sum fold over 32 keys of one class: key = class*128 + m, m = 32 q + r
+    ge running = ge_identity(), total = ge_identity();
+    for (int r = G2; r >= 1; r--) {
+        const u32 k = tid * G2 + r;
+        const u32 kend = cursor[k], kbeg = cursor[k - 1];
+        if (kbeg != kend) {
+            ge_add_nc(running, running, bsum[k - 1]);
+            u32 t = (u32)(((u64)kbeg * MSM_T) / E);
+            for (; t < MSM_T; t++) {
+                const u32 ct = (u32)(((u64)t * E) / MSM_T);
+                if (ct >= kend) break;
+                const u32 ct1 = (u32)(((u64)(t + 1) * E) / MSM_T);
+                if (ct > kbeg && ct1 > ct) ge_add_nc(running, running, psum[t]);
+            }
+        }
+        ge_add_nc(total, total, running);
+    }
+    // class result = sum_q total_q + 32 * sum_{q>=1} suffix_q over the class's 4 lanes
+    const int q = tid & 3;
+    lds_put(stage, tid, running);
+    __syncthreads();
+    ge suf = running;
+    for (int d = 1; d < 4; d++)
+        if (q + d < 4) {
+            ge other = lds_get(stage, tid + d);
+            ge_add_nc(suf, suf, other);
+        }
+    ge x = total;
+    if (q >= 1) {
+        for (int i = 0; i < 5; i++) ge_dbl_nc(suf, suf);
+        ge_add_nc(x, x, suf);
+    }
+    __syncthreads();
+    lds_put(stage, tid, x);
+    __syncthreads();
+    if (q == 0) {
+        for (int d = 1; d < 4; d++) {
+            ge other = lds_get(stage, tid + d);
+            ge_add_nc(x, x, other);
+        }
+        out[msm * FOLD_CLS + (tid >> 2)] = x;
+    }
+}
+
+int32_t fold_generators_launch(bbp_ctx* ctx, uint32_t n_proofs, const sc* g_dev, const sc* h_dev, ge* out_dev, hipStream_t stream,
+                               int scratch_slot) {
+    if (n_proofs == 0) return BBP_OK;
+    const size_t n_msm = 2 * (size_t)n_proofs;
+    const size_t sorted_bytes = ((n_msm * 2048 * FOLD_W * sizeof(u32)) + 255) / 256 * 256;
+    DevBuf& scratch = ctx->slice_fold[scratch_slot];
+    int32_t rc = dev_reserve(ctx, scratch, sorted_bytes + n_msm * (FOLD_K + MSM_T) * sizeof(ge));
+    if (rc) return rc;
+    ge* bsum = reinterpret_cast<ge*>(static_cast<u8*>(scratch.p) + sorted_bytes);
+    ScopedEvent ev(ctx, TAG_MSM, stream);
+    hipLaunchKernelGGL(k_fold_generators, dim3((u32)n_msm), dim3(MSM_T), 0, stream, g_dev, h_dev, ctx->wtable8, (u32*)scratch.p, bsum,
+                       bsum + n_msm * FOLD_K, out_dev);
+    BBP_HIP_TRY(ctx, hipGetLastError());
+    return BBP_OK;
 }
 
 __global__ __launch_bounds__(64) void k_encode(const ge* __restrict__ pts, u32 n, u32* __restrict__ out_words) {

@@ -539,6 +539,7 @@ __global__ __launch_bounds__(IPA_BLK) void k_ipa_round(u32 round, u32 m, const u
         }
         __syncthreads();
     }
+    if (lr_all == nullptr) return;  // tail preparation: only the fold of a, b and the factor update were wanted
     // scalars of L and R; c_L = <a_lo, b_hi>, c_R = <a_hi, b_lo>
     sc* L = lr_all + (size_t)p * 2 * 2049;
     sc* R = L + 2049;
@@ -567,6 +568,155 @@ __global__ __launch_bounds__(IPA_BLK) void k_ipa_round(u32 round, u32 m, const u
         st_sc(&L[2048], sc_mul(c[0], w));
         st_sc(&R[2048], sc_mul(c[1], w));
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// IPA tail on explicit folded generators (rounds FOLD_ROUND..11, vectors of length <= 32)
+// ---------------------------------------------------------------------------------------------------------------
+// signed radix-16 digits of a canonical scalar: d[0..63] in [-8, 8], d[64] = final carry
+__device__ void sc_radix16(const sc& s, int8_t* d) {
+    u32 carry = 0;
+    for (int j = 0; j < 64; j++) {
+        u32 v = ((s.v[j >> 3] >> (4 * (j & 7))) & 15u) + carry;
+        carry = v > 8u;
+        d[j] = (int8_t)(carry ? (int)v - 16 : (int)v);
+    }
+    d[64] = (int8_t)carry;
+}
+
+// s1*P1 + s2*P2 with shared doublings; tab: 16 points of scratch owned by the calling lane (1..8 multiples of each point)
+__device__ ge ge_double_scalarmul(const sc& s1, const ge& P1, const sc& s2, const ge& P2, ge* tab, bool two) {
+    tab[0] = P1;
+    ge cur = P1;
+    for (int i = 1; i < 8; i++) {
+        cur = ge_add(cur, P1);
+        tab[i] = cur;
+    }
+    if (two) {
+        tab[8] = P2;
+        cur = P2;
+        for (int i = 1; i < 8; i++) {
+            cur = ge_add(cur, P2);
+            tab[8 + i] = cur;
+        }
+    }
+    int8_t d1[65], d2[65];
+    sc_radix16(s1, d1);
+    if (two) sc_radix16(s2, d2);
+    ge acc = ge_identity();
+    for (int j = 64; j >= 0; j--) {
+        if (j != 64) {
+            acc = ge_dbl(acc);
+            acc = ge_dbl(acc);
+            acc = ge_dbl(acc);
+            acc = ge_dbl(acc);
+        }
+        int a = d1[j];
+        if (a != 0) {
+            ge q = tab[(a > 0 ? a : -a) - 1];
+            if (a < 0) q = ge_neg(q);
+            acc = ge_add(acc, q);
+        }
+        if (two) {
+            int b = d2[j];
+            if (b != 0) {
+                ge q = tab[8 + (b > 0 ? b : -b) - 1];
+                if (b < 0) q = ge_neg(q);
+                acc = ge_add(acc, q);
+            }
+        }
+    }
+    return acc;
+}
+
+// The tail never folds points either: like the main rounds it keeps per-generator factor scalars (gg, hh: 32 each, stored in
+// the first 32 slots of bd.g / bd.h once the big factor vectors have been consumed by k_fold_generators) and multiplies
+// them into the term scalars.  Every tail round is then ONE launch of 2 x 33 independent scalar multiplications per proof.
+__global__ void k_tail_init(u32 B, sc* __restrict__ g_all, sc* __restrict__ h_all) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * FOLD_CLS) return;
+    const u32 p = t / FOLD_CLS, k = t % FOLD_CLS;
+    st_sc(&g_all[(size_t)p * 2048 + k], sc_one());
+    st_sc(&h_all[(size_t)p * 2048 + k], sc_one());
+}
+
+// between tail rounds (one lane per proof): absorb L, R of `prev_round`, draw u, invert; fold a, b to length n2 and update gg, hh
+__global__ void k_tail_step(u32 B, u32 prev_round, u32 n2, u32 m, const u32* __restrict__ enc, merlin_transcript* __restrict__ tr,
+                            sc* __restrict__ misc, sc* __restrict__ a_all, sc* __restrict__ b_all, sc* __restrict__ g_all, sc* __restrict__ h_all) {
+    u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= B) return;
+    merlin_transcript t = tr[p];
+    const u32* e = enc + (size_t)p * enc_stride_words(m) + 8 * (m + 8) + 16 * (prev_round - 1);
+    tr_append_words(t, LBL("L"), e);
+    tr_append_words(t, LBL("R"), e + 8);
+    const sc u = tr_challenge_sc(t, LBL("u"));
+    const sc ui = sc_invert(u);
+    tr[p] = t;
+    sc *a = a_all + (size_t)p * 2048, *b = b_all + (size_t)p * 2048, *gg = g_all + (size_t)p * 2048, *hh = h_all + (size_t)p * 2048;
+    for (u32 i = 0; i < n2; i++) {
+        sc alo = ld_sc(&a[i]), ahi = ld_sc(&a[n2 + i]), blo = ld_sc(&b[i]), bhi = ld_sc(&b[n2 + i]);
+        st_sc(&a[i], sc_add(sc_mul(alo, u), sc_mul(ui, ahi)));
+        st_sc(&b[i], sc_add(sc_mul(blo, ui), sc_mul(u, bhi)));
+    }
+    for (u32 k = 0; k < FOLD_CLS; k++) {
+        const bool hi = (k & (2 * n2 - 1)) >= n2;
+        st_sc(&gg[k], sc_mul(ld_sc(&gg[k]), hi ? u : ui));
+        st_sc(&hh[k], sc_mul(ld_sc(&hh[k]), hi ? ui : u));
+    }
+}
+
+// L and R of a tail round (half length n <= 16) over the 32 + 32 materialised generators: one lane per (side, term), 33 terms a side.
+//   L = sum_{hi k} a[io] gg[k] F_G[k] + sum_{lo k} b[n+io] hh[k] F_H[k] + c_L w B      (k = blk 2n + {0, n} + io, rank = blk n + io)
+//   R = sum_{lo k} a[n+io] gg[k] F_G[k] + sum_{hi k} b[io] hh[k] F_H[k] + c_R w B
+constexpr int TAIL_BLK = 128;
+__global__ __launch_bounds__(TAIL_BLK) void k_tail_lr(u32 n, const sc* __restrict__ misc, const sc* __restrict__ a_all, const sc* __restrict__ b_all,
+                                                       const sc* __restrict__ g_all, const sc* __restrict__ h_all, const ge* __restrict__ fpts,
+                                                       const ge* __restrict__ gens, ge* __restrict__ vtab, ge* __restrict__ lrpts) {
+    __shared__ u32 stage[GE_WORDS * TAIL_BLK];
+    const u32 p = blockIdx.x, tid = threadIdx.x;
+    const u32 side = tid >> 6, j = tid & 63;  // 64 slots per side, 33 used
+    const sc *a = a_all + (size_t)p * 2048, *b = b_all + (size_t)p * 2048, *gg = g_all + (size_t)p * 2048, *hh = h_all + (size_t)p * 2048;
+    const ge *FG = fpts + (size_t)p * 2 * FOLD_CLS, *FH = FG + FOLD_CLS;
+    constexpr u32 HALF = FOLD_CLS / 2;  // 16 G-terms and 16 H-terms per side
+    ge q = ge_identity();
+    if (j <= 2 * HALF) {
+        sc s;
+        ge P;
+        if (j < 2 * HALF) {
+            const u32 rank = j % HALF, blk = rank / n, io = rank % n;
+            const u32 k_lo = blk * 2 * n + io, k_hi = k_lo + n;
+            if (j < HALF) {  // G term
+                const u32 k = side == 0 ? k_hi : k_lo;
+                s = sc_mul(ld_sc(&a[side == 0 ? io : n + io]), ld_sc(&gg[k]));
+                P = FG[k];
+            } else {  // H term
+                const u32 k = side == 0 ? k_lo : k_hi;
+                s = sc_mul(ld_sc(&b[side == 0 ? n + io : io]), ld_sc(&hh[k]));
+                P = FH[k];
+            }
+        } else {
+            sc c = sc_zero();
+            for (u32 i = 0; i < n; i++)
+                c = sc_add(c, side == 0 ? sc_mul(ld_sc(&a[i]), ld_sc(&b[n + i])) : sc_mul(ld_sc(&a[n + i]), ld_sc(&b[i])));
+            s = sc_mul(c, ld_sc(&misc[(size_t)p * MS_COUNT + MS_W]));  // Q = w B
+            P = gens[BBP_BASE_B];
+        }
+        q = ge_double_scalarmul(s, P, s, P, vtab + ((size_t)p * TAIL_BLK + tid) * 16, false);
+    }
+    const u32* w = reinterpret_cast<const u32*>(&q);
+    for (int k = 0; k < GE_WORDS; k++) stage[k * TAIL_BLK + tid] = w[k];
+    __syncthreads();
+    for (int d = 32; d >= 1; d >>= 1) {
+        if (j < (u32)d) {
+            ge o;
+            u32* ow = reinterpret_cast<u32*>(&o);
+            for (int k = 0; k < GE_WORDS; k++) ow[k] = stage[k * TAIL_BLK + tid + d];
+            q = ge_add(q, o);
+            for (int k = 0; k < GE_WORDS; k++) stage[k * TAIL_BLK + tid] = reinterpret_cast<const u32*>(&q)[k];
+        }
+        __syncthreads();
+    }
+    if (j == 0) lrpts[(size_t)p * 2 + side] = q;
 }
 
 __global__ void k_ipa_final(u32 B, u32 m, const u32* __restrict__ enc, merlin_transcript* __restrict__ tr, sc* __restrict__ misc,
@@ -693,7 +843,7 @@ int32_t batch_reserve(bbp_ctx* ctx, uint32_t B, const CircuitDev& c, BatchDev& b
            o_misc = take(MS_COUNT * S), o_zpow = take(((size_t)c.n_cons + 1) * S), o_ypow = take(2049 * S), o_yipow = take(2048 * S),
            o_wl = take(2048 * S), o_wr = take(2048 * S), o_wo = take(2048 * S), o_wv = take(m * S), o_l1 = take(n1 * S), o_r0 = take(n1 * S),
            o_r1 = take(n1 * S), o_r3 = take(n1 * S), o_a = take(2048 * S), o_b = take(2048 * S), o_g = take(2048 * S), o_h = take(2048 * S),
-           o_lr = take(2 * 2049 * S), o_pts = take((m + 8) * sizeof(ge)), o_lrpts = take(2 * sizeof(ge)),
+           o_lr = take(2 * 2049 * S), o_pts = take((m + 8) * sizeof(ge)), o_lrpts = take(2 * sizeof(ge)), o_fpts = take(2 * FOLD_CLS * sizeof(ge)),
            o_enc = take((m + 8 + 22) * 32), o_ent = take(32 * m + 32);
     int32_t rc = dev_reserve(ctx, buf, off);
     if (rc) return rc;
@@ -709,7 +859,7 @@ int32_t batch_reserve(bbp_ctx* ctx, uint32_t B, const CircuitDev& c, BatchDev& b
     bd.ypow = (sc*)(base + o_ypow); bd.yipow = (sc*)(base + o_yipow); bd.wl = (sc*)(base + o_wl); bd.wr = (sc*)(base + o_wr);
     bd.wo = (sc*)(base + o_wo); bd.wv = (sc*)(base + o_wv); bd.l1 = (sc*)(base + o_l1); bd.r0 = (sc*)(base + o_r0);
     bd.r1 = (sc*)(base + o_r1); bd.r3 = (sc*)(base + o_r3); bd.a = (sc*)(base + o_a); bd.b = (sc*)(base + o_b); bd.g = (sc*)(base + o_g);
-    bd.h = (sc*)(base + o_h); bd.lr = (sc*)(base + o_lr); bd.pts = (ge*)(base + o_pts); bd.lrpts = (ge*)(base + o_lrpts);
+    bd.h = (sc*)(base + o_h); bd.lr = (sc*)(base + o_lr); bd.pts = (ge*)(base + o_pts); bd.lrpts = (ge*)(base + o_lrpts); bd.fpts = (ge*)(base + o_fpts);
     bd.enc = (u32*)(base + o_enc); bd.entropy = base + o_ent;
     return BBP_OK;
 }
@@ -804,7 +954,7 @@ static BatchDev batch_view(const BatchDev& bd, const CircuitDev& c, u32 first) {
     v.cst += f * c.n_cst; v.v += f * m; v.vb += f * m; v.ai1 += f * (1 + 2 * n1); v.ao1 += f * (1 + n1); v.s1 += f * (1 + 2 * n1);
     v.tr += f; v.rng += f; v.misc += f * MS_COUNT; v.zpow += f * ((size_t)c.n_cons + 1); v.ypow += f * 2049; v.yipow += f * 2048;
     v.wl += f * 2048; v.wr += f * 2048; v.wo += f * 2048; v.wv += f * m; v.l1 += f * n1; v.r0 += f * n1; v.r1 += f * n1; v.r3 += f * n1;
-    v.a += f * 2048; v.b += f * 2048; v.g += f * 2048; v.h += f * 2048; v.lr += f * 2 * 2049; v.pts += f * (m + 8); v.lrpts += f * 2;
+    v.a += f * 2048; v.b += f * 2048; v.g += f * 2048; v.h += f * 2048; v.lr += f * 2 * 2049; v.pts += f * (m + 8); v.lrpts += f * 2; v.fpts += f * 2 * FOLD_CLS;
     v.enc += f * (m + 8 + 22) * 8; v.entropy += f * (32 * m + 32);
     return v;
 }
@@ -842,11 +992,30 @@ static int32_t prove_heavy(bbp_ctx* ctx, const CircuitDev& c, const BatchDev& bd
     LAUNCH(ctx, TAG_TRANSCRIPT, k_tr_ux, cdiv(B, 64), 64, s, B, m, n1, bd.enc, bd.wv, bd.vb, bd.ai1, bd.ao1, bd.s1, bd.tr, bd.misc);
     LAUNCH(ctx, TAG_POLY, k_lrvec, cdiv(B * 2048, 128), 128, s, B, n1, bd.l1, bd.r0, bd.r1, bd.r3, bd.ao1, bd.s1, bd.ypow, bd.yipow, bd.misc,
            bd.a, bd.b, bd.g, bd.h);
-    for (u32 r = 1; r <= 11; r++) {
+    const u32 tail_from = (u32)ctx->tail_round;  // FOLD_ROUND (7), or 12 = never leave the fixed-base formulation
+    for (u32 r = 1; r <= 11 && r < tail_from; r++) {
         if (r > 1) LAUNCH(ctx, TAG_TRANSCRIPT, k_ipa_challenge, cdiv(B, 64), 64, s, B, r - 1, m, bd.enc, bd.tr, bd.misc);
         LAUNCH(ctx, TAG_IPA_SCALARS, k_ipa_round, B, IPA_BLK, s, r, m, bd.enc, bd.tr, bd.misc, bd.a, bd.b, bd.g, bd.h, bd.lr);
         if ((rc = msm_launch(ctx, 2 * B, 2049, (const u32*)bd.lr, c.idx_ipa + (size_t)(r - 1) * 2 * 2049, bd.lrpts, s, 2, slot))) return rc;
         LAUNCH(ctx, TAG_ENCODE, k_encode_strided, cdiv(2 * B, 64), 64, s, 2 * B, 2u, bd.lrpts, 2u, bd.enc, encw, 8 * (m + 8 + 2 * (r - 1)));
+    }
+    if (tail_from <= 11) {
+        // switch to explicit folded generators: absorb round FOLD_ROUND-1, fold a, b, update g, h (no scalar rows), then one
+        // composite-bucket pass materialises F_G[32], F_H[32]; the remaining rounds are small variable-base kernels
+        DevBuf& vt = ctx->slice_vtab[slot];
+        if ((rc = dev_reserve(ctx, vt, (size_t)B * TAIL_BLK * 16 * sizeof(ge)))) return rc;
+        ge* vtab = static_cast<ge*>(vt.p);
+        LAUNCH(ctx, TAG_TRANSCRIPT, k_ipa_challenge, cdiv(B, 64), 64, s, B, tail_from - 1, m, bd.enc, bd.tr, bd.misc);
+        LAUNCH(ctx, TAG_IPA_SCALARS, k_ipa_round, B, IPA_BLK, s, tail_from, m, bd.enc, bd.tr, bd.misc, bd.a, bd.b, bd.g, bd.h, (sc*)nullptr);
+        if ((rc = fold_generators_launch(ctx, B, bd.g, bd.h, bd.fpts, s, slot))) return rc;
+        LAUNCH(ctx, TAG_VARBASE, k_tail_init, cdiv(B * FOLD_CLS, 64), 64, s, B, bd.g, bd.h);
+        for (u32 r = tail_from; r <= 11; r++) {
+            const u32 n = 1024u >> (r - 1);
+            if (r > tail_from)
+                LAUNCH(ctx, TAG_TRANSCRIPT, k_tail_step, cdiv(B, 64), 64, s, B, r - 1, 2 * n, m, bd.enc, bd.tr, bd.misc, bd.a, bd.b, bd.g, bd.h);
+            LAUNCH(ctx, TAG_VARBASE, k_tail_lr, B, TAIL_BLK, s, n, bd.misc, bd.a, bd.b, bd.g, bd.h, bd.fpts, ctx->gens, vtab, bd.lrpts);
+            LAUNCH(ctx, TAG_ENCODE, k_encode_strided, cdiv(2 * B, 64), 64, s, 2 * B, 2u, bd.lrpts, 2u, bd.enc, encw, 8 * (m + 8 + 2 * (r - 1)));
+        }
     }
     LAUNCH(ctx, TAG_TRANSCRIPT, k_ipa_final, cdiv(B, 64), 64, s, B, m, bd.enc, bd.tr, bd.misc, bd.a, bd.b);
     LAUNCH(ctx, TAG_TRANSCRIPT, k_assemble, cdiv(B, 64), 64, s, B, m, bd.enc, bd.misc, out_dev);

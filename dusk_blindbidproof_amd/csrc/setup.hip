@@ -28,13 +28,13 @@ __global__ void k_derive_generators(const u32* __restrict__ uniform, ge* __restr
 }
 
 // thread i: table[i*W + j] = affine cached form of 2^(C j) * gens[i]
-__global__ void k_build_wtable(const ge* __restrict__ gens, niels_packed* __restrict__ table) {
+__global__ void k_build_wtable(const ge* __restrict__ gens, niels_packed* __restrict__ table, int windows, int bits) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= BBP_NUM_BASES) return;
     ge p = gens[i];
-    for (int j = 0; j < MSM_W; j++) {
-        table[(size_t)i * MSM_W + j] = niels_pack(ge_to_niels(p, fe_invert(p.Z)));
-        for (int k = 0; k < MSM_C; k++) p = ge_dbl(p);
+    for (int j = 0; j < windows; j++) {
+        table[(size_t)i * windows + j] = niels_pack(ge_to_niels(p, fe_invert(p.Z)));
+        for (int k = 0; k < bits; k++) p = ge_dbl(p);
     }
 }
 
@@ -98,6 +98,7 @@ extern "C" int32_t bbp_init(int32_t device, bbp_ctx** out) {
         BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_stagger[i - 1], hipEventDisableTiming));
     }
     BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_last, hipEventDisableTiming));
+    if (const char* e = getenv("BBP_TAIL_ROUND")) ctx->tail_round = atoi(e) == bbp::FOLD_ROUND ? bbp::FOLD_ROUND : 12;
     if (const char* e = getenv("BBP_STAGGER")) ctx->stagger_mode = atoi(e);
     if (const char* e = getenv("BBP_SLICES")) ctx->slices = atoi(e) < 1 ? 1 : atoi(e) > bbp_ctx::MAX_SLICES ? bbp_ctx::MAX_SLICES : atoi(e);
     for (int i = 0; i < 2; i++) {
@@ -131,7 +132,10 @@ extern "C" int32_t bbp_init(int32_t device, bbp_ctx** out) {
     BBP_HIP_TRY(ctx, hipMemcpyAsync(ctx->mimc_c, ctx->mimc_host.data(), 32 * BBP_MIMC_ROUNDS, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_derive_generators, dim3((BBP_NUM_BASES + 63) / 64), dim3(64), 0, ctx->stream, d_uniform, ctx->gens);
     BBP_HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_build_wtable, dim3((BBP_NUM_BASES + 63) / 64), dim3(64), 0, ctx->stream, ctx->gens, ctx->wtable);
+    hipLaunchKernelGGL(k_build_wtable, dim3((BBP_NUM_BASES + 63) / 64), dim3(64), 0, ctx->stream, ctx->gens, ctx->wtable, (int)MSM_W, (int)MSM_C);
+    BBP_HIP_TRY(ctx, hipGetLastError());
+    BBP_HIP_TRY(ctx, hipMalloc(&ctx->wtable8, sizeof(niels_packed) * (size_t)BBP_NUM_BASES * FOLD_W));
+    hipLaunchKernelGGL(k_build_wtable, dim3((BBP_NUM_BASES + 63) / 64), dim3(64), 0, ctx->stream, ctx->gens, ctx->wtable8, (int)FOLD_W, 8);
     BBP_HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_build_comb, dim3(2), dim3(64), 0, ctx->stream, ctx->gens, ctx->comb);
     BBP_HIP_TRY(ctx, hipGetLastError());
@@ -144,7 +148,8 @@ extern "C" void bbp_free(bbp_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    void* ptrs[] = {ctx->gens, ctx->wtable, ctx->comb, ctx->mimc_c, ctx->scal.p, ctx->idx.p, ctx->sorted.p, ctx->pts.p, ctx->enc.p, ctx->misc.p, ctx->batch.p, ctx->io_in.p, ctx->io_out.p, ctx->io_ent.p, ctx->raw.p, ctx->batch1.p, ctx->slice_sorted[1].p, ctx->slice_sorted[2].p, ctx->slice_sorted[3].p, ctx->slice_pts[1].p, ctx->slice_pts[2].p, ctx->slice_pts[3].p};
+    void* ptrs[] = {ctx->gens, ctx->wtable8, ctx->slice_fold[0].p, ctx->slice_fold[1].p, ctx->slice_fold[2].p, ctx->slice_fold[3].p,
+                    ctx->slice_vtab[0].p, ctx->slice_vtab[1].p, ctx->slice_vtab[2].p, ctx->slice_vtab[3].p, ctx->wtable, ctx->comb, ctx->mimc_c, ctx->scal.p, ctx->idx.p, ctx->sorted.p, ctx->pts.p, ctx->enc.p, ctx->misc.p, ctx->batch.p, ctx->io_in.p, ctx->io_out.p, ctx->io_ent.p, ctx->raw.p, ctx->batch1.p, ctx->slice_sorted[1].p, ctx->slice_sorted[2].p, ctx->slice_sorted[3].p, ctx->slice_pts[1].p, ctx->slice_pts[2].p, ctx->slice_pts[3].p};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int i = 0; i < 2; i++) {
