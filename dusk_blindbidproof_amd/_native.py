@@ -3,7 +3,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-lib_path = os.path.join(_HERE, "libbbp_hip.so")
+# BBP_LIB_VARIANT=name loads libbbp_hip.name.so: experiment builds of the same sources with other -D knobs (tools/build_variant.py)
+_VARIANT = os.environ.get("BBP_LIB_VARIANT", "")
+lib_path = os.path.join(_HERE, "libbbp_hip.%s.so" % _VARIANT if _VARIANT else "libbbp_hip.so")
 
 STATUS = {0: "OK", 1: "VERIFY", 2: "GENS_LEN", 3: "FORMAT", 4: "BAD_ARG", 5: "DEVICE"}
 LAYOUT_BLIND_G_H, LAYOUT_BLIND_G = 0, 1
@@ -44,7 +46,7 @@ class BbpError(RuntimeError):
 
 def _load():
     if not os.path.exists(lib_path):
-        raise ImportError("libbbp_hip.so not built (run `python __graft_entry__.py`); there is no CPU fallback")
+        raise ImportError(os.path.basename(lib_path) + " not built (run `python __graft_entry__.py`); there is no CPU fallback")
     L = ctypes.CDLL(lib_path)
     for name, (res, args) in SIGNATURES.items():
         f = getattr(L, name)  # AttributeError here = the .so does not export what include/bbp.h declares
