@@ -14,18 +14,20 @@
 namespace bbp {
 
 // ---- MSM geometry (see DESIGN.md "K1") ---------------------------------------------------------------
-constexpr int MSM_C = 11;                 // window bits (signed digits in [-1023, 1024])
-constexpr int MSM_W = 24;                 // windows: 24 * 11 = 264 >= 256 bits
-constexpr int MSM_K = 1 << (MSM_C - 1);   // 1024 buckets (|digit| = 1..1024)
+constexpr int MSM_NAF = 12;               // scalar recoding: width-12 NAF, odd digits |d| < 2048
+constexpr int MSM_POS = 256;              // table rows per generator: 2^b * P for every bit position b
+constexpr int MSM_W = 22;                 // most digits one scalar can have (positions >= 12 apart, last <= 253)
+constexpr int MSM_K = 1 << (MSM_NAF - 2); // 1024 buckets: bucket k holds the digit magnitude 2k - 1
 constexpr int MSM_T = 128;                // threads per MSM workgroup (2 wavefronts)
 constexpr int MSM_G = MSM_K / MSM_T;      // 8 consecutive buckets per lane
 constexpr int MSM_LOG_G = 3;
 // IPA tail (prover.hip): from round FOLD_ROUND the folded generators are explicit points; they are materialised by a
-// composite-bucket Pippenger pass over an 8-bit-window row table (msm.hip k_fold_generators)
+// composite-bucket Pippenger pass over the same row table (msm.hip k_fold_generators)
 constexpr int FOLD_ROUND = 7;              // first tail round: vectors of length 32 (halves of 16)
 constexpr int FOLD_CLS = 2048 >> (FOLD_ROUND - 1);  // 32 folded generators per side
-constexpr int FOLD_W = 32;                 // 8-bit windows
-constexpr int FOLD_M = 128;                // |digit| values
+constexpr int FOLD_NAF = 9;                // width-9 NAF: odd digits |d| < 256
+constexpr int FOLD_W = 29;                 // most digits per scalar
+constexpr int FOLD_M = 128;                // buckets per class
 constexpr int FOLD_K = FOLD_CLS * FOLD_M;  // 4096 composite buckets
 constexpr int GE_WORDS = sizeof(ge) / 4;  // 40: a point in registers / LDS / scratch
 
@@ -58,8 +60,7 @@ struct bbp_ctx {
     std::string err;
     // resident tables
     bbp::ge* gens = nullptr;           // [BBP_NUM_BASES] extended points: B_blinding, G[2048], H[2048], B
-    bbp::niels_packed* wtable8 = nullptr;  // [BBP_NUM_BASES * FOLD_W] 2^(8 j) * P_i rows for the generator-folding pass
-    bbp::niels_packed* wtable = nullptr;   // [BBP_NUM_BASES * MSM_W] affine cached 2^(11 j) * P_i
+    bbp::niels_row* ptable = nullptr;      // [BBP_NUM_BASES * MSM_POS] affine cached 2^b * P_i, 128-byte limb rows (134 MB)
     bbp::niels_packed* comb = nullptr;     // [2][64][8] radix-16 comb for B and B_blinding (small commits)
     bbp::sc* mimc_c = nullptr;         // [90]
     uint8_t gens_enc_host_valid = 0;

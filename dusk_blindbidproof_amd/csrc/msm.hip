@@ -5,19 +5,25 @@
 // Verifier::verify, reached from src/blindbid/proof.rs:88 and src/blindbid/verify.rs:88.  Any evaluation order
 // gives the same group element, and the ristretto encoding is canonical, so outputs are byte-identical.
 //
+// The table holds EVERY power-of-two multiple 2^b * P_i (b = 0..255) of every generator as a 128-byte row of ready-to-use
+// limbs, so a scalar can be recoded in width-12 non-adjacent form: odd digits |d| < 2048 at arbitrary bit positions, one
+// non-zero digit per 13 bits on average (19.5 per scalar instead of the 24 of aligned 11-bit windows), 1024 buckets, and
+// no doublings anywhere.  The hot loop is instruction-issue bound (measured: serving all rows from cache changes its time
+// by 7 %), so fewer additions and no unpacking are what count; the 134 MB of rows are HBM/MALL resident.
+//
 // One workgroup (2 wavefronts, 128 lanes) owns one MSM:
-//   A. signed 11-bit digits of every scalar -> LDS histogram over |digit| (1024 buckets)
+//   A. NAF digits of every scalar -> LDS histogram over bucket (|d| + 1) / 2
 //   B. exclusive scan -> bucket offsets (each lane owns 8 consecutive buckets)
-//   C. counting-sort scatter of (table index, sign) into the workgroup's HBM scratch slice
-//   D. each lane walks its 8 buckets high->low: bucket sum by mixed additions of cached affine table entries
-//      2^(11 j) * P_i (no doublings anywhere: the window shift is precomputed in the table), then the classic
-//      running-sum fold (running += bucket; total += running)
-//   E. cross-lane fold through LDS: suffix scan of the lane sums, weight by 8, tree reduce.
+//   C. counting-sort scatter of (row index, sign) into the workgroup's HBM scratch slice
+//   D1. the sorted entry array is cut into 128 equal chunks, one per lane: mixed additions of table rows into bucket sums
+//   D2. running-sum fold over the lane's 8 buckets
+//   E. cross-lane fold (shuffles): W = sum_k k S_k and S = sum_k S_k; result = sum_k (2k - 1) S_k = 2 W - S
 #include "context.h"
 
 namespace bbp {
 
-// resident waves per SIMD the register allocator aims the MSM kernels at (512 VGPRs / waves)
+// resident waves per SIMD the register allocator aims the MSM kernels at (512 VGPRs / waves).  Measured on the blind-bid
+// batch: 2 (no spills) beats 3 and 4 (spills in the cold phases, nothing gained in the issue-bound hot loop).
 #ifndef BBP_MSM_WAVES
 #define BBP_MSM_WAVES 2
 #endif
@@ -38,8 +44,7 @@ __device__ unsigned long long g_msm_prof[8];
 #endif
 
 // Cross-lane exchange of a point: within a wavefront through ds_bpermute (no LDS storage), between the two wavefronts of a
-// workgroup through one 40-word LDS slot.  Keeping LDS down to the 4 KB of bucket cursors is what lets all 8 workgroups a CU
-// gets from a 2048-MSM launch be resident together (4 waves per SIMD, the VGPR limit) instead of 5 and then 3.
+// workgroup through one 40-word LDS slot.
 __device__ __forceinline__ ge ge_shfl_down(const ge& p, int d) {
     ge r;
     const u32* w = reinterpret_cast<const u32*>(&p);
@@ -63,76 +68,51 @@ __device__ __forceinline__ ge xch_get(const u32* xch) {
     return p;
 }
 
-__device__ __forceinline__ niels_packed load_raw(const niels_packed* __restrict__ tab, u32 entry) {
-    // the row index is clamped: a corrupted scratch entry must never turn into an out-of-bounds gather (a GPU fault here
-    // takes the whole node down); one v_min_u32 per 2000-instruction iteration
-    const u32 row = min(entry & 0x7fffffffu, (u32)(BBP_NUM_BASES * MSM_W - 1));
+// one 128-byte row, one cache line.  The index is clamped: a corrupted scratch entry must never turn into an out-of-bounds
+// gather (a GPU fault here takes the whole node down); one v_min_u32 per ~1400-instruction iteration.
+__device__ __forceinline__ niels_row load_row(const niels_row* __restrict__ tab, u32 entry) {
+    const u32 row = min(entry & 0x7fffffffu, (u32)(BBP_NUM_BASES * MSM_POS - 1));
     const uint4* p = reinterpret_cast<const uint4*>(tab + row);
-    uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4], q5 = p[5];
-    niels_packed r = {{q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w,
-                       q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w}};
+    uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4], q5 = p[5], q6 = p[6], q7 = p[7];
+    niels_row r = {{(i32)q0.x, (i32)q0.y, (i32)q0.z, (i32)q0.w, (i32)q1.x, (i32)q1.y, (i32)q1.z, (i32)q1.w, (i32)q2.x, (i32)q2.y, (i32)q2.z,
+                    (i32)q2.w, (i32)q3.x, (i32)q3.y, (i32)q3.z, (i32)q3.w, (i32)q4.x, (i32)q4.y, (i32)q4.z, (i32)q4.w, (i32)q5.x, (i32)q5.y,
+                    (i32)q5.z, (i32)q5.w, (i32)q6.x, (i32)q6.y, (i32)q6.z, (i32)q6.w, (i32)q7.x, (i32)q7.y, (i32)q7.z, (i32)q7.w}};
     return r;
 }
 
-__device__ __forceinline__ niels_packed load_raw8(const niels_packed* __restrict__ tab, u32 entry) {
-    const u32 row = min(entry & 0x7fffffffu, (u32)(BBP_NUM_BASES * FOLD_W - 1));
-    const uint4* p = reinterpret_cast<const uint4*>(tab + row);
-    uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4], q5 = p[5];
-    niels_packed r = {{q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w,
-                       q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w}};
-    return r;
-}
-
-// keeps the compiler from sinking a computation past this point (it must materialise the limbs in registers here)
-__device__ __forceinline__ void pin_regs(ge_niels& n) {
+// acc +/- row: mixed addition (7M); the sign swaps the roles of y+x / y-x and of D - C / D + C
+__device__ __forceinline__ ge ge_madd_row(const ge& p, const niels_row& q, bool neg) {
+    fe ypx, ymx, xy2d;
 #pragma unroll
     for (int i = 0; i < 10; i++) {
-        asm volatile("" : "+v"(n.ypx.v[i]));
-        asm volatile("" : "+v"(n.ymx.v[i]));
-        asm volatile("" : "+v"(n.xy2d.v[i]));
+        ypx.v[i] = neg ? q.v[10 + i] : q.v[i];
+        ymx.v[i] = neg ? q.v[i] : q.v[10 + i];
+        xy2d.v[i] = q.v[20 + i];
     }
-}
-
-// packed row -> limbs; a negative digit uses -(x, y) = (-x, y): swap y+x / y-x and negate 2dxy
-__device__ __forceinline__ ge_niels unpack_niels(const niels_packed& r, u32 neg) {
-    ge_niels n;
-    fe a = fe_fromwords(r.w), b = fe_fromwords(r.w + 8), c = fe_fromwords(r.w + 16);
-    n.ypx = fe_select(a, b, neg != 0);
-    n.ymx = fe_select(b, a, neg != 0);
-    n.xy2d = fe_select(c, fe_neg(c), neg != 0);
-    return n;
+    fe a = fe_mul(fe_sub(p.Y, p.X), ymx);
+    fe b = fe_mul(fe_add(p.Y, p.X), ypx);
+    fe c = fe_mul(p.T, xy2d);
+    fe d = fe_add(p.Z, p.Z);
+    fe e = fe_sub(b, a), h = fe_add(b, a);
+    fe f0 = fe_sub(d, c), g0 = fe_add(d, c);
+    fe f = fe_select(f0, g0, neg), g = fe_select(g0, f0, neg);
+    ge r;
+    r.X = fe_mul(e, f);
+    r.Y = fe_mul(g, h);
+    r.Z = fe_mul(f, g);
+    r.T = fe_mul(e, h);
+    return r;
 }
 
 // The cold phases (bucket fold, cross-lane reduction) call ONE out-of-line copy of the point addition / doubling: inlining
-// them at seven sites made the kernel 124 KB, and with workgroups of a CU in different phases the 64 KB instruction cache
+// them at every site made the kernel 124 KB, and with workgroups of a CU in different phases the 64 KB instruction cache
 // thrashed under the hot mixed-addition loop (measured: that loop ran 1.7x slower than the same code in isolation).
 __device__ __noinline__ void ge_add_nc(ge& r, const ge& a, const ge& b) { r = ge_add(a, b); }
 __device__ __noinline__ void ge_dbl_nc(ge& r, const ge& a) { r = ge_dbl(a); }
 
-// signed-digit walk over one scalar; calls f(j, magnitude, negative) for every non-zero digit
-template <class F>
-__device__ __forceinline__ void for_each_digit(const u32 (&s)[8], F&& f) {
-    u32 carry = 0;
-#pragma unroll
-    for (int j = 0; j < MSM_W; j++) {
-        const int o = j * MSM_C, w = o >> 5, sh = o & 31;
-        u32 raw = 0;
-        if (w < 8) {
-            raw = s[w] >> sh;
-            if (sh + MSM_C > 32 && w + 1 < 8) raw |= s[w + 1] << (32 - sh);
-        }
-        raw &= (1u << MSM_C) - 1u;
-        u32 d = raw + carry;
-        carry = d > (u32)MSM_K;
-        u32 mag = carry ? (2u * MSM_K - d) : d;
-        if (mag) f(j, mag, carry);
-    }
-}
-
-__global__ __launch_bounds__(MSM_T) __attribute__((amdgpu_waves_per_eu(BBP_MSM_WAVES, BBP_MSM_WAVES))) void k_msm(const u32* __restrict__ scalars, const u32* __restrict__ base_idx_sets, u32 n,
-                                                u32 n_idx_sets, const niels_packed* __restrict__ wtable,
-                                                u32* __restrict__ sorted_all, ge* __restrict__ bsum_all, ge* __restrict__ psum_all,
-                                                ge* __restrict__ out) {
+__global__ __launch_bounds__(MSM_T) __attribute__((amdgpu_waves_per_eu(BBP_MSM_WAVES, BBP_MSM_WAVES)))
+void k_msm(const u32* __restrict__ scalars, const u32* __restrict__ base_idx_sets, u32 n, u32 n_idx_sets, const niels_row* __restrict__ ptable,
+           u32* __restrict__ sorted_all, ge* __restrict__ bsum_all, ge* __restrict__ psum_all, ge* __restrict__ out) {
     __shared__ u32 cursor[MSM_K + 1];  // histogram, then bucket start offsets, then (after the scatter) bucket end offsets
     __shared__ u32 part[MSM_T];
     __shared__ u32 xch[GE_WORDS];
@@ -151,7 +131,7 @@ __global__ __launch_bounds__(MSM_T) __attribute__((amdgpu_waves_per_eu(BBP_MSM_W
         const uint4* sp = reinterpret_cast<const uint4*>(sbase + (size_t)i * 8);
         uint4 lo = sp[0], hi = sp[1];
         const u32 s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        for_each_digit(s, [&](int, u32 mag, u32) { atomicAdd(&cursor[mag], 1u); });
+        sc_for_each_naf_digit<MSM_NAF>(s, [&](u32, u32 mag, u32) { atomicAdd(&cursor[(mag + 1) >> 1], 1u); });
     }
     __syncthreads();
     MSM_PROF_MARK(0);
@@ -189,10 +169,10 @@ __global__ __launch_bounds__(MSM_T) __attribute__((amdgpu_waves_per_eu(BBP_MSM_W
         const uint4* sp = reinterpret_cast<const uint4*>(sbase + (size_t)i * 8);
         uint4 lo = sp[0], hi = sp[1];
         const u32 s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        const u32 tb = base_idx[i] * MSM_W;
-        for_each_digit(s, [&](int j, u32 mag, u32 neg) {
-            u32 pos = atomicAdd(&cursor[mag], 1u);
-            sorted[pos] = (tb + (u32)j) | (neg << 31);
+        const u32 tb = base_idx[i] * MSM_POS;
+        sc_for_each_naf_digit<MSM_NAF>(s, [&](u32 pos, u32 mag, u32 neg) {
+            u32 at = atomicAdd(&cursor[(mag + 1) >> 1], 1u);
+            sorted[at] = (tb + pos) | (neg << 31);
         });
     }
     __threadfence_block();
@@ -219,28 +199,24 @@ __global__ __launch_bounds__(MSM_T) __attribute__((amdgpu_waves_per_eu(BBP_MSM_W
         u32 k = lo, kend = cursor[k];
         ge* dest = (cursor[k - 1] < c0) ? &psum[tid] : &bsum[k - 1];
         ge acc = ge_identity();
-        // software pipeline, two deep: the entry index is fetched two iterations ahead and the 96-byte table row one
-        // iteration ahead, so neither load is waited for before a full mixed addition (~2000 instructions) has run
+        // software pipeline, two deep: the entry index is fetched two iterations ahead and the 128-byte table row one
+        // iteration ahead, so neither load is waited for before a full mixed addition (~1300 instructions) has run
         u32 ent_cur = sorted[c0];
         u32 ent_nxt = (c0 + 1 < c1) ? sorted[c0 + 1] : 0u;
-        niels_packed raw = load_raw(wtable, ent_cur);
+        niels_row row = load_row(ptable, ent_cur);
         for (u32 e = c0; e < c1; e++) {
-            // order matters: gfx9 has ONE counter for loads and stores, so the wait that guards `raw` also waits for whatever
-            // was stored since.  Unpacking first (its loads completed during the previous addition) leaves the bucket-crossing
-            // store to drain under the ~2000 instructions of the next addition instead of being waited for on the spot.
-            ge_niels cur = unpack_niels(raw, ent_cur >> 31);
-            pin_regs(cur);
-            asm volatile("" : "+v"(ent_nxt));
             if (e == kend) {  // crossed into the next non-empty bucket
                 *dest = acc;
                 acc = ge_identity();
                 do { k++; kend = cursor[k]; } while (kend == e);
                 dest = &bsum[k - 1];
             }
+            const niels_row cur = row;
+            const bool neg = ent_cur >> 31;
             ent_cur = ent_nxt;
-            if (e + 1 < c1) raw = load_raw(wtable, ent_cur);
+            if (e + 1 < c1) row = load_row(ptable, ent_cur);
             if (e + 2 < c1) ent_nxt = sorted[e + 2];
-            acc = ge_madd(acc, cur);
+            acc = ge_madd_row(acc, cur, neg);
         }
         *dest = acc;
     }
@@ -269,7 +245,7 @@ __global__ __launch_bounds__(MSM_T) __attribute__((amdgpu_waves_per_eu(BBP_MSM_W
     }
 
     MSM_PROF_MARK(4);
-    // E. cross-lane fold: R = sum_t total_t + 8 * sum_{t>=1} suffix_t, suffix_t = sum_{u>=t} running_u
+    // E. cross-lane fold: W = sum_k k S_k = sum_t total_t + 8 * sum_{t>=1} suffix_t, suffix_t = sum_{u>=t} running_u
     const int lane = tid & 63, wave = tid >> 6;
     for (int d = 1; d < 64; d <<= 1) {  // suffix scan inside each wavefront
         ge other = ge_shfl_down(running, d);
@@ -297,8 +273,12 @@ __global__ __launch_bounds__(MSM_T) __attribute__((amdgpu_waves_per_eu(BBP_MSM_W
     if (tid == 0) {
         ge other = xch_get(xch);
         ge_add_nc(x, x, other);
+        // bucket k holds the digit 2k - 1: result = 2 W - S, S = suffix_0 = lane 0's running
+        ge_dbl_nc(x, x);
+        other = ge_neg(running);
+        ge_add_nc(x, x, other);
+        out[msm] = x;
     }
-    if (tid == 0) out[msm] = x;
     MSM_PROF_MARK(5);
 }
 
@@ -308,24 +288,12 @@ __global__ __launch_bounds__(MSM_T) __attribute__((amdgpu_waves_per_eu(BBP_MSM_W
 // From round FOLD_ROUND on, the IPA vectors are at most 32 long, and two 2049-term fixed-base MSMs per round cost far more
 // than working with the 32 + 32 explicit folded generators F_G[i] = sum_{k = i mod 32} g[k] G[k] (and F_H likewise).
 // This kernel computes those 32 sums of one side (G or H) of one proof in ONE Pippenger pass with COMPOSITE buckets
-// key = class(k) * 128 + |digit| (8-bit signed digits, 32 windows, row table 2^(8 j) P): same histogram / counting sort /
-// balanced accumulation as k_msm, then a running-sum fold per class (4 lanes of 32 keys each).
+// key = class(k) * 128 + (|digit| + 1) / 2 over width-9 NAF digits (odd, < 256) and the same row table: histogram /
+// counting sort / balanced accumulation as in k_msm, then a running-sum fold per class (4 lanes of 32 keys each).
 // ---------------------------------------------------------------------------------------------------------------
-template <class F>
-__device__ __forceinline__ void for_each_digit8(const u32 (&s)[8], F&& f) {
-    u32 carry = 0;
-#pragma unroll
-    for (int j = 0; j < FOLD_W; j++) {
-        u32 d = ((s[j >> 2] >> (8 * (j & 3))) & 0xffu) + carry;
-        carry = d > 128u;
-        u32 mag = carry ? 256u - d : d;
-        if (mag) f(j, mag, carry);
-    }  // scalars are < 2^253: byte 31 never carries out
-}
-
-__global__ __launch_bounds__(MSM_T) __attribute__((amdgpu_waves_per_eu(BBP_MSM_WAVES, BBP_MSM_WAVES))) void k_fold_generators(const sc* __restrict__ g_all, const sc* __restrict__ h_all,
-                                                            const niels_packed* __restrict__ wtable8, u32* __restrict__ sorted_all,
-                                                            ge* __restrict__ bsum_all, ge* __restrict__ psum_all, ge* __restrict__ out) {
+__global__ __launch_bounds__(MSM_T) __attribute__((amdgpu_waves_per_eu(BBP_MSM_WAVES, BBP_MSM_WAVES)))
+void k_fold_generators(const sc* __restrict__ g_all, const sc* __restrict__ h_all, const niels_row* __restrict__ ptable,
+                       u32* __restrict__ sorted_all, ge* __restrict__ bsum_all, ge* __restrict__ psum_all, ge* __restrict__ out) {
     __shared__ u32 cursor[FOLD_K + 1];
     __shared__ u32 part[MSM_T];
     const int tid = threadIdx.x;
@@ -343,7 +311,7 @@ __global__ __launch_bounds__(MSM_T) __attribute__((amdgpu_waves_per_eu(BBP_MSM_W
         uint4 lo = sp[0], hi = sp[1];
         const u32 s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
         const u32 cls = (i & (FOLD_CLS - 1)) * FOLD_M;
-        for_each_digit8(s, [&](int, u32 mag, u32) { atomicAdd(&cursor[cls + mag], 1u); });
+        sc_for_each_naf_digit<FOLD_NAF>(s, [&](u32, u32 mag, u32) { atomicAdd(&cursor[cls + ((mag + 1) >> 1)], 1u); });
     }
     __syncthreads();
     {
@@ -373,10 +341,10 @@ __global__ __launch_bounds__(MSM_T) __attribute__((amdgpu_waves_per_eu(BBP_MSM_W
         uint4 lo = sp[0], hi = sp[1];
         const u32 s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
         const u32 cls = (i & (FOLD_CLS - 1)) * FOLD_M;
-        const u32 tb = (base0 + i) * FOLD_W;
-        for_each_digit8(s, [&](int j, u32 mag, u32 neg) {
-            u32 pos = atomicAdd(&cursor[cls + mag], 1u);
-            sorted[pos] = (tb + (u32)j) | (neg << 31);
+        const u32 tb = (base0 + i) * MSM_POS;
+        sc_for_each_naf_digit<FOLD_NAF>(s, [&](u32 pos, u32 mag, u32 neg) {
+            u32 at = atomicAdd(&cursor[cls + ((mag + 1) >> 1)], 1u);
+            sorted[at] = (tb + pos) | (neg << 31);
         });
     }
     __threadfence_block();
@@ -399,21 +367,20 @@ __global__ __launch_bounds__(MSM_T) __attribute__((amdgpu_waves_per_eu(BBP_MSM_W
         ge acc = ge_identity();
         u32 ent_cur = sorted[c0];
         u32 ent_nxt = (c0 + 1 < c1) ? sorted[c0 + 1] : 0u;
-        niels_packed raw = load_raw8(wtable8, ent_cur);
+        niels_row row = load_row(ptable, ent_cur);
         for (u32 e = c0; e < c1; e++) {
-            ge_niels cur = unpack_niels(raw, ent_cur >> 31);  // before the crossing store: see k_msm
-            pin_regs(cur);
-            asm volatile("" : "+v"(ent_nxt));
             if (e == kend) {
                 *dest = acc;
                 acc = ge_identity();
                 do { k++; kend = cursor[k]; } while (kend == e);
                 dest = &bsum[k - 1];
             }
+            const niels_row cur = row;
+            const bool neg = ent_cur >> 31;
             ent_cur = ent_nxt;
-            if (e + 1 < c1) raw = load_raw8(wtable8, ent_cur);
+            if (e + 1 < c1) row = load_row(ptable, ent_cur);
             if (e + 2 < c1) ent_nxt = sorted[e + 2];
-            acc = ge_madd(acc, cur);
+            acc = ge_madd_row(acc, cur, neg);
         }
         *dest = acc;
     }
@@ -437,7 +404,7 @@ __global__ __launch_bounds__(MSM_T) __attribute__((amdgpu_waves_per_eu(BBP_MSM_W
         }
         ge_add_nc(total, total, running);
     }
-    // class result = sum_q total_q + 32 * sum_{q>=1} suffix_q over the class's 4 lanes
+    // class: W = sum_q total_q + 32 * sum_{q>=1} suffix_q and S = suffix_0 over the class's 4 lanes; result = 2 W - S
     const int q = tid & 3;
     ge suf = running;
     for (int d = 1; d < 4; d++) {
@@ -446,15 +413,21 @@ __global__ __launch_bounds__(MSM_T) __attribute__((amdgpu_waves_per_eu(BBP_MSM_W
     }
     ge x = total;
     if (q >= 1) {
-        for (int i = 0; i < 5; i++) ge_dbl_nc(suf, suf);
-        ge_add_nc(x, x, suf);
+        ge s32 = suf;
+        for (int i = 0; i < 5; i++) ge_dbl_nc(s32, s32);
+        ge_add_nc(x, x, s32);
     }
     ge acc4 = x;
     for (int d = 1; d < 4; d++) {
         ge other = ge_shfl_down(x, d);
         if (q == 0) ge_add_nc(acc4, acc4, other);
     }
-    if (q == 0) out[msm * FOLD_CLS + (tid >> 2)] = acc4;
+    if (q == 0) {
+        ge_dbl_nc(acc4, acc4);
+        ge other = ge_neg(suf);
+        ge_add_nc(acc4, acc4, other);
+        out[msm * FOLD_CLS + (tid >> 2)] = acc4;
+    }
 }
 
 int32_t fold_generators_launch(bbp_ctx* ctx, uint32_t n_proofs, const sc* g_dev, const sc* h_dev, ge* out_dev, hipStream_t stream,
@@ -467,7 +440,7 @@ int32_t fold_generators_launch(bbp_ctx* ctx, uint32_t n_proofs, const sc* g_dev,
     if (rc) return rc;
     ge* bsum = reinterpret_cast<ge*>(static_cast<u8*>(scratch.p) + sorted_bytes);
     ScopedEvent ev(ctx, TAG_MSM, stream);
-    hipLaunchKernelGGL(k_fold_generators, dim3((u32)n_msm), dim3(MSM_T), 0, stream, g_dev, h_dev, ctx->wtable8, (u32*)scratch.p, bsum,
+    hipLaunchKernelGGL(k_fold_generators, dim3((u32)n_msm), dim3(MSM_T), 0, stream, g_dev, h_dev, ctx->ptable, (u32*)scratch.p, bsum,
                        bsum + n_msm * FOLD_K, out_dev);
     BBP_HIP_TRY(ctx, hipGetLastError());
     return BBP_OK;
@@ -502,15 +475,15 @@ int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* sc
     if (rc) return rc;
     ge* bsum = reinterpret_cast<ge*>(static_cast<u8*>(scratch.p) + msm_sorted_bytes(n_msm, n_terms));
     ScopedEvent ev(ctx, TAG_MSM, stream);
-    hipLaunchKernelGGL(k_msm, dim3(n_msm), dim3(MSM_T), 0, stream, scalars_dev, base_idx_dev, n_terms, n_idx_sets, ctx->wtable,
+    hipLaunchKernelGGL(k_msm, dim3(n_msm), dim3(MSM_T), 0, stream, scalars_dev, base_idx_dev, n_terms, n_idx_sets, ctx->ptable,
                        (u32*)scratch.p, bsum, bsum + (size_t)n_msm * MSM_K, out_points_dev);
     BBP_HIP_TRY(ctx, hipGetLastError());
 #ifdef BBP_MSM_PROF
     static int launches = 0;
     if (++launches % 16 == 0) {
         unsigned long long h[8];
-        hipStreamSynchronize(stream);
-        hipMemcpyFromSymbol(h, HIP_SYMBOL(g_msm_prof), sizeof h);
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_msm_prof), sizeof h);
         fprintf(stderr, "[msm prof, %d launches, 10ns ticks of lane 0 summed over WGs] A %llu BC %llu D1 %llu D1wait %llu D2 %llu E %llu\n", launches,
                 h[0], h[1], h[2], h[3], h[4], h[5]);
     }

@@ -21,12 +21,29 @@ struct niels_packed {  // the same three field elements as canonical 8-word valu
     u32 w[24];
 };
 
+struct alignas(128) niels_row {  // MSM table row: ypx[10] | ymx[10] | xy2d[10] | pad[2] as canonical limbs, one cache line
+    i32 v[32];
+};
+
 BBP_HD niels_packed niels_pack(const ge_niels& n) {
     niels_packed p;
     fe_towords(p.w, n.ypx);
     fe_towords(p.w + 8, n.ymx);
     fe_towords(p.w + 16, n.xy2d);
     return p;
+}
+
+BBP_HD niels_row niels_to_row(const ge_niels& n) {
+    niels_row r;
+    u32 w[8];
+    const fe* src[3] = {&n.ypx, &n.ymx, &n.xy2d};
+    for (int k = 0; k < 3; k++) {  // through the canonical words: limbs come out non-negative and fully carried
+        fe_towords(w, *src[k]);
+        fe c = fe_fromwords(w);
+        for (int i = 0; i < 10; i++) r.v[10 * k + i] = c.v[i];
+    }
+    r.v[30] = r.v[31] = 0;
+    return r;
 }
 
 BBP_HD ge ge_identity() {

@@ -204,4 +204,32 @@ BBP_HD void sc_tobytes(uint8_t* out, const sc& a) {
     }
 }
 
+// Width-WID non-adjacent form of a 256-bit little-endian value < 2^253 (the MSM kernels' scalar recoding), least significant
+// digit first: calls f(position, |digit|, negative) for every digit; digits are odd, |digit| < 2^(WID-1), consecutive positions
+// at least WID apart, last position <= 253, on average one digit per WID + 1 bits.
+// An "effective" bit is bit + carry: runs where bit == carry are skipped with one find-first-set.
+template <int WID, class F>
+BBP_HD void sc_for_each_naf_digit(const u32 (&s)[8], F&& f) {
+    u32 carry = 0;
+    int off = 0;  // bit offset into the current 32-bit word (may run past it)
+#pragma unroll
+    for (int wi = 0; wi < 8; wi++) {
+        const u64 win = (u64)s[wi] | (wi + 1 < 8 ? (u64)s[wi + 1] << 32 : 0ull);
+        while (off < 32) {
+            const u64 rest = (win ^ (carry ? ~0ull : 0ull)) >> off;
+            if (rest == 0) {
+                off = 64;
+                break;
+            }
+            off += __builtin_ctzll(rest);
+            if (off >= 32) break;
+            const u32 t = ((u32)(win >> off) & ((1u << WID) - 1u)) + carry;  // odd, <= 2^WID - 1
+            carry = t >> (WID - 1);
+            f((u32)(32 * wi + off), carry ? (1u << WID) - t : t, carry);
+            off += WID;
+        }
+        off -= 32;
+    }
+}
+
 }  // namespace bbp

@@ -27,14 +27,17 @@ __global__ void k_derive_generators(const u32* __restrict__ uniform, ge* __restr
     gens[i] = ge_from_uniform_words(w);  // 0: B_blinding, 1..2048: G, 2049..4096: H
 }
 
-// thread i: table[i*W + j] = affine cached form of 2^(C j) * gens[i]
-__global__ void k_build_wtable(const ge* __restrict__ gens, niels_packed* __restrict__ table, int windows, int bits) {
-    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= BBP_NUM_BASES) return;
+// thread (i, c): rows 16c .. 16c+15 of generator i: table[i*256 + b] = affine cached form of 2^b * gens[i]
+constexpr int PT_CHUNK = 16;
+__global__ void k_build_ptable(const ge* __restrict__ gens, niels_row* __restrict__ table) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= BBP_NUM_BASES * (MSM_POS / PT_CHUNK)) return;
+    const u32 i = t / (MSM_POS / PT_CHUNK), c = t % (MSM_POS / PT_CHUNK);
     ge p = gens[i];
-    for (int j = 0; j < windows; j++) {
-        table[(size_t)i * windows + j] = niels_pack(ge_to_niels(p, fe_invert(p.Z)));
-        for (int k = 0; k < bits; k++) p = ge_dbl(p);
+    for (u32 k = 0; k < c * PT_CHUNK; k++) p = ge_dbl(p);
+    for (u32 b = c * PT_CHUNK; b < (c + 1) * PT_CHUNK; b++) {
+        table[(size_t)i * MSM_POS + b] = niels_to_row(ge_to_niels(p, fe_invert(p.Z)));
+        p = ge_dbl(p);
     }
 }
 
@@ -126,16 +129,13 @@ extern "C" int32_t bbp_init(int32_t device, bbp_ctx** out) {
     BBP_HIP_TRY(ctx, hipMalloc(&d_uniform, uniform.size()));
     BBP_HIP_TRY(ctx, hipMemcpyAsync(d_uniform, uniform.data(), uniform.size(), hipMemcpyHostToDevice, ctx->stream));
     BBP_HIP_TRY(ctx, hipMalloc(&ctx->gens, sizeof(ge) * BBP_NUM_BASES));
-    BBP_HIP_TRY(ctx, hipMalloc(&ctx->wtable, sizeof(niels_packed) * (size_t)BBP_NUM_BASES * MSM_W));
+    BBP_HIP_TRY(ctx, hipMalloc(&ctx->ptable, sizeof(niels_row) * (size_t)BBP_NUM_BASES * MSM_POS));
     BBP_HIP_TRY(ctx, hipMalloc(&ctx->comb, sizeof(niels_packed) * 2 * 64 * 8));
     BBP_HIP_TRY(ctx, hipMalloc(&ctx->mimc_c, sizeof(sc) * BBP_MIMC_ROUNDS));
     BBP_HIP_TRY(ctx, hipMemcpyAsync(ctx->mimc_c, ctx->mimc_host.data(), 32 * BBP_MIMC_ROUNDS, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_derive_generators, dim3((BBP_NUM_BASES + 63) / 64), dim3(64), 0, ctx->stream, d_uniform, ctx->gens);
     BBP_HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_build_wtable, dim3((BBP_NUM_BASES + 63) / 64), dim3(64), 0, ctx->stream, ctx->gens, ctx->wtable, (int)MSM_W, (int)MSM_C);
-    BBP_HIP_TRY(ctx, hipGetLastError());
-    BBP_HIP_TRY(ctx, hipMalloc(&ctx->wtable8, sizeof(niels_packed) * (size_t)BBP_NUM_BASES * FOLD_W));
-    hipLaunchKernelGGL(k_build_wtable, dim3((BBP_NUM_BASES + 63) / 64), dim3(64), 0, ctx->stream, ctx->gens, ctx->wtable8, (int)FOLD_W, 8);
+    hipLaunchKernelGGL(k_build_ptable, dim3((BBP_NUM_BASES * (MSM_POS / PT_CHUNK) + 63) / 64), dim3(64), 0, ctx->stream, ctx->gens, ctx->ptable);
     BBP_HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_build_comb, dim3(2), dim3(64), 0, ctx->stream, ctx->gens, ctx->comb);
     BBP_HIP_TRY(ctx, hipGetLastError());
@@ -148,8 +148,8 @@ extern "C" void bbp_free(bbp_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    void* ptrs[] = {ctx->gens, ctx->wtable8, ctx->slice_fold[0].p, ctx->slice_fold[1].p, ctx->slice_fold[2].p, ctx->slice_fold[3].p,
-                    ctx->slice_vtab[0].p, ctx->slice_vtab[1].p, ctx->slice_vtab[2].p, ctx->slice_vtab[3].p, ctx->wtable, ctx->comb, ctx->mimc_c, ctx->scal.p, ctx->idx.p, ctx->sorted.p, ctx->pts.p, ctx->enc.p, ctx->misc.p, ctx->batch.p, ctx->io_in.p, ctx->io_out.p, ctx->io_ent.p, ctx->raw.p, ctx->batch1.p, ctx->slice_sorted[1].p, ctx->slice_sorted[2].p, ctx->slice_sorted[3].p, ctx->slice_pts[1].p, ctx->slice_pts[2].p, ctx->slice_pts[3].p};
+    void* ptrs[] = {ctx->gens, ctx->ptable, ctx->slice_fold[0].p, ctx->slice_fold[1].p, ctx->slice_fold[2].p, ctx->slice_fold[3].p,
+                    ctx->slice_vtab[0].p, ctx->slice_vtab[1].p, ctx->slice_vtab[2].p, ctx->slice_vtab[3].p, ctx->comb, ctx->mimc_c, ctx->scal.p, ctx->idx.p, ctx->sorted.p, ctx->pts.p, ctx->enc.p, ctx->misc.p, ctx->batch.p, ctx->io_in.p, ctx->io_out.p, ctx->io_ent.p, ctx->raw.p, ctx->batch1.p, ctx->slice_sorted[1].p, ctx->slice_sorted[2].p, ctx->slice_sorted[3].p, ctx->slice_pts[1].p, ctx->slice_pts[2].p, ctx->slice_pts[3].p};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int i = 0; i < 2; i++) {

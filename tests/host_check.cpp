@@ -41,6 +41,21 @@ void hc_fe_op(int op, const uint8_t* a32, const uint8_t* b32, uint8_t* out32) {
     fe_tobytes(out32, r);
 }
 
+// NAF recoding used by the MSM kernels: writes (position, signed digit) pairs, returns the count (width 12 or 9)
+int hc_sc_naf(int width, const uint8_t* a32, int32_t* pos_out, int32_t* digit_out) {
+    u32 w[8];
+    ld(w, a32, 8);
+    int n = 0;
+    auto emit = [&](u32 pos, u32 mag, u32 neg) {
+        pos_out[n] = (int32_t)pos;
+        digit_out[n] = neg ? -(int32_t)mag : (int32_t)mag;
+        n++;
+    };
+    if (width == 12) sc_for_each_naf_digit<12>(w, emit);
+    else sc_for_each_naf_digit<9>(w, emit);
+    return n;
+}
+
 // op: 0 add, 1 sub, 2 mul, 3 invert, 4 from_wide(a64), 5 from_bits(a32), 6 neg
 void hc_sc_op(int op, const uint8_t* a, const uint8_t* b32, uint8_t* out32) {
     sc x, y, r;

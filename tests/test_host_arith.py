@@ -99,6 +99,27 @@ BAD_ENCODINGS = [
     "445425117cb8c90edcbc7c1cc0e74f747f2c1efa5630a967c64f287792a48a4b", "ffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffff7f"]
 
 
+def test_naf_recoding(lib):
+    """sc_for_each_naf_digit (the MSM kernels' scalar recoding): value, oddness, magnitude, spacing, position and count bounds"""
+    rnd = random.Random(7)
+    vals = [0, 1, 2, 3, L - 1, L - 2, 2**252, 2**253 - 1, 2**252 - 1, (2**253 - 1) // 3, 0xfff, 0x800, 0x7ff, 2**200 - 1,
+            int("10" * 126, 2), int("01" * 126, 2), (1 << 253) - (1 << 241), sum(1 << (13 * i) for i in range(19))]
+    vals += [rnd.getrandbits(253) for _ in range(3000)] + [rnd.getrandbits(rnd.randrange(1, 253)) for _ in range(500)]
+    total = {12: 0, 9: 0}
+    for width, max_digits in ((12, 22), (9, 29)):
+        pos = (ctypes.c_int32 * 64)()
+        dig = (ctypes.c_int32 * 64)()
+        for v in vals:
+            n = lib.hc_sc_naf(width, b32(v), pos, dig)
+            assert n <= max_digits
+            assert sum(dig[i] << pos[i] for i in range(n)) == v
+            for i in range(n):
+                assert dig[i] & 1 and abs(dig[i]) < (1 << (width - 1)) and 0 <= pos[i] <= 253
+                assert i == 0 or pos[i] >= pos[i - 1] + width
+            total[width] += n
+    assert total[12] / len(vals) < 20.5 and total[9] / len(vals) < 26.5  # ~253/13 and ~253/10 digits on average
+
+
 def test_point_ops_and_codec(lib):
     rnd = random.Random(3)
     out = ctypes.create_string_buffer(32)
