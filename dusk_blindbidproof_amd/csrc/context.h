@@ -47,6 +47,8 @@ struct bbp_ctx {
     hipEvent_t ev_join[MAX_SLICES] = {nullptr, nullptr, nullptr, nullptr}, ev_stagger[MAX_SLICES] = {nullptr, nullptr, nullptr, nullptr};
     int slices = 2;
     int tail_round = bbp::FOLD_ROUND;  // first IPA round run on explicit folded generators (BBP_TAIL_ROUND=12 disables)
+    int serial_lds = 160 * 1024;  // LDS the one-lane-per-proof opening kernels reserve to keep their CU to themselves (BBP_SERIAL_LDS, 0 = off)
+    std::map<const void*, int> serial_attr;
     int stagger_mode = 0;  // 0: slices start together, 1: next slice starts after this slice's first MSM, 3: after its third (BBP_STAGGER)
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_open[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     bool ev_done_valid[2] = {false, false}, ev_open_valid[2] = {false, false};
@@ -121,6 +123,9 @@ struct ScopedEvent {  // records start now, stop at scope exit, when profiling i
         if (idx >= 0) (void)hipEventRecord(ctx->events[idx].b, s);
     }
 };
+
+// see prover.hip "serial_lds_bytes": kernels that must not share a CU with the long-lived serial waves ask for a few bytes of LDS
+inline unsigned lds_token(const bbp_ctx* ctx) { return ctx->serial_lds >= 160 * 1024 ? 64u : 0u; }
 
 inline int32_t stream_guard_enter(bbp_ctx* ctx, hipStream_t s) {
     if (ctx->ev_last_valid && ctx->last_stream != s) BBP_HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_last, 0));

@@ -121,6 +121,9 @@ void k_msm(const u32* __restrict__ scalars, const u32* __restrict__ base_idx_set
     const u32* sbase = scalars + msm * (size_t)n * 8;
     u32* sorted = sorted_all + msm * (size_t)n * MSM_W;
     const u32* base_idx = base_idx_sets + (size_t)(blockIdx.x % n_idx_sets) * n;
+#ifdef BBP_MSM_PRIO
+    __builtin_amdgcn_s_setprio(BBP_MSM_PRIO);
+#endif
     MSM_PROF_BEGIN();
 
     for (int k = tid; k <= MSM_K; k += MSM_T) cursor[k] = 0;
@@ -494,7 +497,7 @@ int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* sc
 int32_t encode_launch(bbp_ctx* ctx, uint32_t n, const ge* pts_dev, uint8_t* out32_dev, hipStream_t stream) {
     if (n == 0) return BBP_OK;
     ScopedEvent ev(ctx, TAG_ENCODE, stream);
-    hipLaunchKernelGGL(k_encode, dim3((n + 63) / 64), dim3(64), 0, stream, pts_dev, n, (u32*)out32_dev);
+    hipLaunchKernelGGL(k_encode, dim3((n + 63) / 64), dim3(64), lds_token(ctx), stream, pts_dev, n, (u32*)out32_dev);
     BBP_HIP_TRY(ctx, hipGetLastError());
     return BBP_OK;
 }

@@ -872,12 +872,30 @@ static merlin_transcript prover_prefix() {
     return t;
 }
 
-#define LAUNCH(ctx, tag, kern, grid, block, stream, ...)                             \
-    do {                                                                             \
-        ScopedEvent _ev(ctx, tag, stream);                                           \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, stream, __VA_ARGS__);   \
-        BBP_HIP_TRY(ctx, hipGetLastError());                                         \
+#define LAUNCH_LDS(ctx, tag, kern, grid, block, lds, stream, ...)                        \
+    do {                                                                                 \
+        ScopedEvent _ev(ctx, tag, stream);                                               \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, stream, __VA_ARGS__);     \
+        BBP_HIP_TRY(ctx, hipGetLastError());                                             \
     } while (0)
+// every other launch carries a token 64 bytes of LDS so that it, too, stays off the fully reserved CUs
+#define LAUNCH(ctx, tag, kern, grid, block, stream, ...) LAUNCH_LDS(ctx, tag, kern, grid, block, lds_token(ctx), stream, __VA_ARGS__)
+
+// The one-lane-per-proof kernels of the opening stage (k_witness, k_tr_open: 16 wavefronts that run for tens of
+// milliseconds) overlap the previous batch's heavy stage.  Sharing a SIMD with them is poison for that stage: the long-lived
+// wave is the oldest on its SIMD and wins issue arbitration, the MSM workgroup next to it runs several times slower, and
+// since a 1024-workgroup launch is placed in one round, every kernel then lasts as long as its slowest workgroup (measured:
+// k_msm 3.3 ms -> 19.5 ms while k_tr_open is resident; 107 ms -> 78 ms per batch without it).  So these launches ask for
+// nearly a whole CU's LDS, which they never touch: no LDS-using workgroup (every heavy kernel that matters) can be placed
+// beside them, the dispatcher routes those to the other ~240 CUs, and the serial wave has its CU to itself.
+static int32_t serial_lds_bytes(bbp_ctx* ctx, const void* kernel) {
+    if (ctx->serial_lds <= 0) return 0;
+    if (!ctx->serial_attr.count(kernel)) {
+        BBP_HIP_TRY(ctx, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->serial_lds));
+        ctx->serial_attr[kernel] = 1;
+    }
+    return BBP_OK;
+}
 
 static inline u32 cdiv(u32 a, u32 b) { return (a + b - 1) / b; }
 
@@ -911,12 +929,14 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
         // made (include/bbp.h).  Waiting on the caller's stream tail would serialise it behind the previous call's heavy stage.
         if (ctx->ev_done_valid[par]) BBP_HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_done[par], 0));
         LAUNCH(ctx, TAG_WITNESS, k_fill_mimc, cdiv(B * BBP_MIMC_ROUNDS, 64), 64, s, B, c.n_cst, ctx->mimc_c, bd.cst);
-        LAUNCH(ctx, TAG_WITNESS, k_witness, cdiv(B, 64), 64, s, B, N, n1, c.n_cst, in_dev, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v, bd.ai1,
-               bd.ao1, 1);
+        if ((rc = serial_lds_bytes(ctx, (const void*)k_witness)) || (rc = serial_lds_bytes(ctx, (const void*)k_tr_open))) return rc;
+        const u32 hog = ctx->serial_lds > 0 ? (u32)ctx->serial_lds : 0u;
+        LAUNCH_LDS(ctx, TAG_WITNESS, k_witness, cdiv(B, 64), 64, hog, s, B, N, n1, c.n_cst, in_dev, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v,
+                   bd.ai1, bd.ao1, 1);
         LAUNCH(ctx, TAG_TRANSCRIPT, k_load_blindings, cdiv(B * m, 64), 64, s, B, m, ent_dev, bd.vb);
         if ((rc = commit_launch(ctx, B * m, bd.v, bd.vb, m, m, m, bd.pts, m + 8, s))) return rc;
         LAUNCH(ctx, TAG_ENCODE, k_encode_strided, cdiv(B * m, 64), 64, s, B * m, m, bd.pts, m + 8, bd.enc, encw, 0u);
-        LAUNCH(ctx, TAG_RNG, k_tr_open, cdiv(B, 64), 64, s, B, m, n1, prefix, bd.enc, ent_dev, bd.vb, (u32*)ctx->raw.p, bd.tr, bd.rng);
+        LAUNCH_LDS(ctx, TAG_RNG, k_tr_open, cdiv(B, 64), 64, hog, s, B, m, n1, prefix, bd.enc, ent_dev, bd.vb, (u32*)ctx->raw.p, bd.tr, bd.rng);
         LAUNCH(ctx, TAG_RNG, k_reduce_draws, cdiv((u32)(B * n_draws), 128), 128, s, B, n1, (const u32*)ctx->raw.p, bd.ai1, bd.ao1, bd.s1);
         BBP_HIP_TRY(ctx, hipEventRecord(ctx->ev_open[par], s));
         ctx->ev_open_valid[par] = true;

@@ -103,6 +103,7 @@ extern "C" int32_t bbp_init(int32_t device, bbp_ctx** out) {
     BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_last, hipEventDisableTiming));
     if (const char* e = getenv("BBP_TAIL_ROUND")) ctx->tail_round = atoi(e) == bbp::FOLD_ROUND ? bbp::FOLD_ROUND : 12;
     if (const char* e = getenv("BBP_STAGGER")) ctx->stagger_mode = atoi(e);
+    if (const char* e = getenv("BBP_SERIAL_LDS")) ctx->serial_lds = atoi(e) < 0 ? 0 : atoi(e) > 160 * 1024 ? 160 * 1024 : atoi(e);
     if (const char* e = getenv("BBP_SLICES")) ctx->slices = atoi(e) < 1 ? 1 : atoi(e) > bbp_ctx::MAX_SLICES ? bbp_ctx::MAX_SLICES : atoi(e);
     for (int i = 0; i < 2; i++) {
         BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_in[i], hipEventDisableTiming));
