@@ -66,9 +66,9 @@ def roofline(wl, timings, steps, alu_peak=None):
            "alg_bytes_per_launch": alg_per_launch,
            "note": "modular-integer path: the binding roofline is 32-bit integer multiply issue, not HBM (DESIGN.md section 5)"}
     if alu_peak:
-        # secondary, honest roofline (SURVEY.md 7 hard part 2): table-row additions per second against the register-resident
-        # mixed-addition rate measured live by bbp_ubench (no memory traffic).  One 160-byte term = 23 non-zero 11-bit digits.
-        adds = alg_per_launch / 160.0 * 23.0 / (avg_us * 1e-6) if avg_us > 0 else 0.0
+        # secondary, honest roofline (SURVEY.md 7 hard part 2): table-row additions the MSM kernels actually perform per second
+        # (one per non-zero NAF digit) against the register-resident mixed-addition rate bbp_ubench measures live (no memory traffic)
+        adds = wl.row_additions_per_step * steps / (sum(dom) * 1e-6) if dom else 0.0
         out["alu"] = {"bound": "v_mad_i64_i32 issue", "achieved": adds, "peak": alu_peak, "unit": "point additions/s",
                       "frac": adds / alu_peak}
     return out

@@ -73,6 +73,16 @@ def _kernel_table(timings):
     return {k: {"launches": v[0], "total_us": round(v[1], 1)} for k, v in agg.items()}
 
 
+# average non-zero digits per scalar of the engine's recodings (tests/test_host_arith.py::test_naf_recoding measures them):
+# width-12 NAF in k_msm, width-9 NAF in k_fold_generators; one digit = one table-row addition
+NAF12_DIGITS, NAF9_DIGITS = 19.85, 25.66
+
+
+# HBM bytes per k_msm launch from the rocprofv3 PMC passes on B = 1024, N = 8 (profiles/README.md): FETCH_SIZE x 2 (gfx950
+# reports half of wide reads, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, averaged over the step's MSM launches
+MEASURED_TRAFFIC_PROVE_1024_8 = (2 * 2755095 + 1732449) * 1024  # profiles/r01_rocprofv3_pmc_hbm.csv, k_msm
+
+
 class _Base:
     dominant_tag = 1
     dominant_kernel = "k_msm"
@@ -103,10 +113,11 @@ class MsmWorkload(_Base):
         terms = sum(n for n, _ in self.shapes)
         # 160 B read per term (32 B scalar + 128 B extended point) + 32 B written per MSM
         self.alg_bytes_per_step = batch * (terms * 160 + 32 * len(self.shapes))
+        self.row_additions_per_step = batch * terms * NAF12_DIGITS
         self.dominant_launches_per_step = len(self.shapes)
         self.config = {"workload": "configs[1]: batch of %d blind-bid proofs, commitment MSMs only (N=%d: %s terms)"
                        % (batch, items, "+".join(str(n) for n, _ in self.shapes)),
-                       "batch_per_gpu": batch, "bid_list_len": items, "msm_window_bits": 11, "parallelism": "batch-sharded"}
+                       "batch_per_gpu": batch, "bid_list_len": items, "msm_recoding": "NAF-12", "parallelism": "batch-sharded"}
 
     def step(self, stream):
         for (n, layout), s, o in zip(self.shapes, self.scal, self.out):
@@ -154,17 +165,21 @@ class ProveWorkload(_Base):
         self.units_per_step = batch
         n1 = 1442 + 3 * items
         commit_terms = (1 + 2 * n1) * 2 + (1 + n1)
-        ipa_terms = 22 * 2049
-        # the engine's k_msm launches per prove step: 3 commitment launches + 11 IPA launches (2 MSMs per proof each)
-        self.alg_bytes_per_step = batch * ((commit_terms + ipa_terms) * 160 + 32 * (3 + 22))
-        self.dominant_launches_per_step = 3 + 11
+        # the REFERENCE algorithm's MSM terms per prove (V, A_I1, A_O1, S1, T, Q, IPA L/R with shrinking halves, generator
+        # folds) at 160 B read per term + 32 B per output point: 23 766 terms = 3.80 MB per proof at N = 8
+        ref_terms = 2 * (4 + items) + 5 * n1 + 3 + 11 + 8210 + 8188
+        self.alg_bytes_per_step = batch * (ref_terms * 160 + 32 * ((4 + items) + 8 + 22))
+        # what the engine's MSM kernels actually add (fold-free IPA: rounds 1-6 are 2 x 2049-term MSMs over the original generators,
+        # then one composite-bucket pass over all 4096 generators; the tail rounds are variable-base work outside k_msm)
+        engine_terms = commit_terms + 6 * 2 * 2049
+        self.row_additions_per_step = batch * (engine_terms * NAF12_DIGITS + 4096 * NAF9_DIGITS)
+        self.dominant_launches_per_step = 3 + 6 + 1
+        self.measured_traffic_bytes = None  # set from profiles/ (rocprofv3 PMC passes) for the B = 1024, N = 8 configuration
         if batch == 1024 and items == 8:
-            # rocprofv3 PMC passes on this exact configuration (profiles/r01_rocprofv3_pmc_hbm.csv): per k_msm launch
-            # FETCH_SIZE 2 616 069 KiB (x2: gfx950 reports half of wide reads, MI355X_MICROARCH.md HBM) + WRITE_SIZE 1 952 272 KiB
-            self.measured_traffic_bytes = (2 * 2616069 + 1952272) * 1024
+            self.measured_traffic_bytes = MEASURED_TRAFFIC_PROVE_1024_8
         self.config = {"workload": "configs[2]: batch of %d full blind-bid R1CS proves (N=%d, 1466 multipliers, 11 IPA rounds)" % (batch, items),
-                       "batch_per_gpu": batch, "bid_list_len": items, "msm_window_bits": 11, "parallelism": "batch-sharded",
-                       "msm_terms_per_proof": commit_terms + ipa_terms}
+                       "batch_per_gpu": batch, "bid_list_len": items, "msm_recoding": "NAF-12", "parallelism": "batch-sharded",
+                       "ref_msm_terms_per_proof": ref_terms, "engine_msm_terms_per_proof": engine_terms + 4096}
 
     def step(self, stream):
         self.ctx.prove_batch_dev(self.B, self.N, self.in_dev.data_ptr(), self.ent_dev.data_ptr(), self.out_dev.data_ptr(), stream)
@@ -228,7 +243,8 @@ class VerifyWorkload(_Base):
         self.ent_dev = _to_dev(torch, device, hashlib.shake_256(b"verifier-entropy%d" % seed).digest(32 * batch))
         self.status = torch.full((batch,), -1, dtype=torch.int32, device=device)
         self.units_per_step = batch
-        self.alg_bytes_per_step = batch * (4098 * 160 + 32)   # the fixed-base mega-check MSM launch
+        self.alg_bytes_per_step = batch * ((4135 + items) * 160 + 32)   # verify = 4135 + N terms
+        self.row_additions_per_step = batch * 4098 * NAF12_DIGITS      # the fixed-base mega-check MSM launch
         self.dominant_launches_per_step = 1
         self.config = {"workload": "batch of %d full blind-bid verifications (N=%d), %d corrupted" % (batch, items, len(self.bad)),
                        "batch_per_gpu": batch, "bid_list_len": items, "parallelism": "batch-sharded"}

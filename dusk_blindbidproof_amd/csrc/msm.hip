@@ -71,7 +71,10 @@ __device__ __forceinline__ ge xch_get(const u32* xch) {
 // one 128-byte row, one cache line.  The index is clamped: a corrupted scratch entry must never turn into an out-of-bounds
 // gather (a GPU fault here takes the whole node down); one v_min_u32 per ~1400-instruction iteration.
 __device__ __forceinline__ niels_row load_row(const niels_row* __restrict__ tab, u32 entry) {
-    const u32 row = min(entry & 0x7fffffffu, (u32)(BBP_NUM_BASES * MSM_POS - 1));
+    u32 row = min(entry & 0x7fffffffu, (u32)(BBP_NUM_BASES * MSM_POS - 1));
+#ifdef BBP_EXP_ROWMASK  // experiment (wrong results): alias all gathers onto a cache-resident slice of the table
+    row &= BBP_EXP_ROWMASK;
+#endif
     const uint4* p = reinterpret_cast<const uint4*>(tab + row);
     uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4], q5 = p[5], q6 = p[6], q7 = p[7];
     niels_row r = {{(i32)q0.x, (i32)q0.y, (i32)q0.z, (i32)q0.w, (i32)q1.x, (i32)q1.y, (i32)q1.z, (i32)q1.w, (i32)q2.x, (i32)q2.y, (i32)q2.z,

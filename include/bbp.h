@@ -64,7 +64,9 @@ int32_t bbp_msm_batch(bbp_ctx* ctx, uint32_t B, uint32_t n_terms, const uint8_t*
 
 /* Device-resident variant used by bench.py so the timed region starts with inputs in HBM: same semantics with
  * `scalars_dev` / `out32_dev` being device pointers; `stream` is a hipStream_t (0 = context stream); does not
- * synchronise.  bbp_msm_workspace_bytes() tells the caller how much scratch bbp_msm_batch_dev will use. */
+ * synchronise.  The device scalars cannot be screened on the host: they MUST be canonical (< l < 2^253) -- the recoding
+ * only looks at bits 0..255 and silently drops a final carry, so a non-canonical scalar yields a wrong point (never a fault).
+ * Scratch is grown inside the context on first use of a batch shape. */
 int32_t bbp_msm_batch_dev(bbp_ctx* ctx, uint32_t B, uint32_t n_terms, const void* scalars_dev, uint32_t layout,
                           void* out32_dev, void* stream);
 
