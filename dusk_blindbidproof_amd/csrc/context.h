@@ -48,6 +48,7 @@ struct bbp_ctx {
     int slices = 2;
     int tail_round = bbp::FOLD_ROUND;  // first IPA round run on explicit folded generators (BBP_TAIL_ROUND=12 disables)
     int serial_lds = 160 * 1024;  // LDS the one-lane-per-proof opening kernels reserve to keep their CU to themselves (BBP_SERIAL_LDS, 0 = off)
+    int serial_block = 64;        // threads per workgroup of those kernels: 256 = one serial wave per SIMD of the reserved CU (BBP_SERIAL_BLOCK)
     std::map<const void*, int> serial_attr;
     int stagger_mode = 0;  // 0: slices start together, 1: next slice starts after this slice's first MSM, 3: after its third (BBP_STAGGER)
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_open[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
@@ -63,6 +64,7 @@ struct bbp_ctx {
     // resident tables
     bbp::ge* gens = nullptr;           // [BBP_NUM_BASES] extended points: B_blinding, G[2048], H[2048], B
     bbp::niels_row* ptable = nullptr;      // [BBP_NUM_BASES * MSM_POS] affine cached 2^b * P_i, 128-byte limb rows (134 MB)
+    bbp::ge* btab = nullptr;               // [32] m * 2^(64 k) * B, m = 1..8, k = 0..3 (prover.hip tail rounds)
     bbp::niels_packed* comb = nullptr;     // [2][64][8] radix-16 comb for B and B_blinding (small commits)
     bbp::sc* mimc_c = nullptr;         // [90]
     uint8_t gens_enc_host_valid = 0;
@@ -146,5 +148,7 @@ int32_t fold_generators_launch(bbp_ctx* ctx, uint32_t n_proofs, const sc* g_dev,
                                int scratch_slot);
 int32_t encode_launch(bbp_ctx* ctx, uint32_t n, const ge* pts_dev, uint8_t* out32_dev, hipStream_t stream);
 size_t msm_scratch_bytes(uint32_t n_msm, uint32_t n_terms);
+// prover.hip
+int32_t tail_btab_build(bbp_ctx* ctx);
 
 }  // namespace bbp

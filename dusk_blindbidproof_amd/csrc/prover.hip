@@ -629,6 +629,57 @@ __device__ ge ge_double_scalarmul(const sc& s1, const ge& P1, const sc& s2, cons
     return acc;
 }
 
+// Tail tables: for a point P the multiples m * 2^(64 k) * P, m = 1..8, k = 0..3 (32 extended points).  A scalar multiplication
+// over such a table is 60 doublings + 64 additions (signed radix-16 digits, four 64-bit pieces sharing the doublings) instead of
+// 252 + 64 + 7, and the tables of the 64 materialised generators are built once and used by all five tail rounds.
+constexpr int TAIL_TAB = 32;
+__global__ void k_tail_tables(u32 count, const ge* __restrict__ pts, ge* __restrict__ tab) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    ge P = pts[t];
+    ge* T = tab + (size_t)t * TAIL_TAB;
+    for (int k = 0; k < 4; k++) {
+        ge cur = P;
+        T[8 * k] = P;
+        for (int i = 1; i < 8; i++) {
+            cur = ge_add(cur, P);
+            T[8 * k + i] = cur;
+        }
+        if (k < 3)
+            for (int i = 0; i < 64; i++) P = ge_dbl(P);
+    }
+}
+
+__device__ ge ge_scalarmul_pieces(const sc& s, const ge* __restrict__ T) {
+    // carry mask of the signed radix-16 recoding: bit j = carry INTO digit j (a canonical scalar never carries out of digit 63)
+    u64 cm = 0;
+    u32 c = 0;
+    for (int j = 0; j < 64; j++) {
+        u32 v = ((s.v[j >> 3] >> (4 * (j & 7))) & 15u) + c;
+        c = v > 8u;
+        if (j < 63) cm |= (u64)c << (j + 1);
+    }
+    ge acc = ge_identity();
+    for (int r = 15; r >= 0; r--) {
+        if (r != 15) {
+            acc = ge_dbl(acc);
+            acc = ge_dbl(acc);
+            acc = ge_dbl(acc);
+            acc = ge_dbl(acc);
+        }
+        for (int k = 0; k < 4; k++) {
+            const int j = 16 * k + r;
+            const int d = (int)((s.v[j >> 3] >> (4 * (j & 7))) & 15u) + (int)((cm >> j) & 1u) - 16 * (int)((j < 63) ? ((cm >> (j + 1)) & 1u) : 0u);
+            if (d != 0) {
+                ge q = T[8 * k + (d > 0 ? d : -d) - 1];
+                if (d < 0) q = ge_neg(q);
+                acc = ge_add(acc, q);
+            }
+        }
+    }
+    return acc;
+}
+
 // The tail never folds points either: like the main rounds it keeps per-generator factor scalars (gg, hh: 32 each, stored in
 // the first 32 slots of bd.g / bd.h once the big factor vectors have been consumed by k_fold_generators) and multiplies
 // them into the term scalars.  Every tail round is then ONE launch of 2 x 33 independent scalar multiplications per proof.
@@ -670,38 +721,38 @@ __global__ void k_tail_step(u32 B, u32 prev_round, u32 n2, u32 m, const u32* __r
 //   R = sum_{lo k} a[n+io] gg[k] F_G[k] + sum_{hi k} b[io] hh[k] F_H[k] + c_R w B
 constexpr int TAIL_BLK = 128;
 __global__ __launch_bounds__(TAIL_BLK) void k_tail_lr(u32 n, const sc* __restrict__ misc, const sc* __restrict__ a_all, const sc* __restrict__ b_all,
-                                                       const sc* __restrict__ g_all, const sc* __restrict__ h_all, const ge* __restrict__ fpts,
-                                                       const ge* __restrict__ gens, ge* __restrict__ vtab, ge* __restrict__ lrpts) {
+                                                       const sc* __restrict__ g_all, const sc* __restrict__ h_all, const ge* __restrict__ ftab,
+                                                       const ge* __restrict__ btab, ge* __restrict__ lrpts) {
     __shared__ u32 stage[GE_WORDS * TAIL_BLK];
     const u32 p = blockIdx.x, tid = threadIdx.x;
     const u32 side = tid >> 6, j = tid & 63;  // 64 slots per side, 33 used
     const sc *a = a_all + (size_t)p * 2048, *b = b_all + (size_t)p * 2048, *gg = g_all + (size_t)p * 2048, *hh = h_all + (size_t)p * 2048;
-    const ge *FG = fpts + (size_t)p * 2 * FOLD_CLS, *FH = FG + FOLD_CLS;
+    const ge *FG = ftab + (size_t)p * 2 * FOLD_CLS * TAIL_TAB, *FH = FG + (size_t)FOLD_CLS * TAIL_TAB;  // tables of F_G[32], F_H[32]
     constexpr u32 HALF = FOLD_CLS / 2;  // 16 G-terms and 16 H-terms per side
     ge q = ge_identity();
     if (j <= 2 * HALF) {
         sc s;
-        ge P;
+        const ge* T;
         if (j < 2 * HALF) {
             const u32 rank = j % HALF, blk = rank / n, io = rank % n;
             const u32 k_lo = blk * 2 * n + io, k_hi = k_lo + n;
             if (j < HALF) {  // G term
                 const u32 k = side == 0 ? k_hi : k_lo;
                 s = sc_mul(ld_sc(&a[side == 0 ? io : n + io]), ld_sc(&gg[k]));
-                P = FG[k];
+                T = FG + (size_t)k * TAIL_TAB;
             } else {  // H term
                 const u32 k = side == 0 ? k_lo : k_hi;
                 s = sc_mul(ld_sc(&b[side == 0 ? n + io : io]), ld_sc(&hh[k]));
-                P = FH[k];
+                T = FH + (size_t)k * TAIL_TAB;
             }
         } else {
             sc c = sc_zero();
             for (u32 i = 0; i < n; i++)
                 c = sc_add(c, side == 0 ? sc_mul(ld_sc(&a[i]), ld_sc(&b[n + i])) : sc_mul(ld_sc(&a[n + i]), ld_sc(&b[i])));
             s = sc_mul(c, ld_sc(&misc[(size_t)p * MS_COUNT + MS_W]));  // Q = w B
-            P = gens[BBP_BASE_B];
+            T = btab;
         }
-        q = ge_double_scalarmul(s, P, s, P, vtab + ((size_t)p * TAIL_BLK + tid) * 16, false);
+        q = ge_scalarmul_pieces(s, T);
     }
     const u32* w = reinterpret_cast<const u32*>(&q);
     for (int k = 0; k < GE_WORDS; k++) stage[k * TAIL_BLK + tid] = w[k];
@@ -899,6 +950,13 @@ static int32_t serial_lds_bytes(bbp_ctx* ctx, const void* kernel) {
 
 static inline u32 cdiv(u32 a, u32 b) { return (a + b - 1) / b; }
 
+int32_t tail_btab_build(bbp_ctx* ctx) {  // called once from bbp_init: the table of B for the c w B term of the tail rounds
+    BBP_HIP_TRY(ctx, hipMalloc(&ctx->btab, sizeof(ge) * TAIL_TAB));
+    hipLaunchKernelGGL(k_tail_tables, dim3(1), dim3(64), 0, ctx->stream, 1u, ctx->gens + BBP_BASE_B, ctx->btab);
+    BBP_HIP_TRY(ctx, hipGetLastError());
+    return BBP_OK;
+}
+
 static BatchDev batch_view(const BatchDev& bd, const CircuitDev& c, u32 first);
 static int32_t prove_heavy(bbp_ctx* ctx, const CircuitDev& c, const BatchDev& bd, u32 B, u8* out_dev, hipStream_t s, int slot,
                            hipEvent_t stagger);
@@ -931,12 +989,14 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
         LAUNCH(ctx, TAG_WITNESS, k_fill_mimc, cdiv(B * BBP_MIMC_ROUNDS, 64), 64, s, B, c.n_cst, ctx->mimc_c, bd.cst);
         if ((rc = serial_lds_bytes(ctx, (const void*)k_witness)) || (rc = serial_lds_bytes(ctx, (const void*)k_tr_open))) return rc;
         const u32 hog = ctx->serial_lds > 0 ? (u32)ctx->serial_lds : 0u;
-        LAUNCH_LDS(ctx, TAG_WITNESS, k_witness, cdiv(B, 64), 64, hog, s, B, N, n1, c.n_cst, in_dev, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v,
+        // 4 waves per workgroup: one serial wave per SIMD, a quarter as many CUs taken out of the heavy stage's pool
+        const u32 sblk = hog ? (u32)ctx->serial_block : 64u;
+        LAUNCH_LDS(ctx, TAG_WITNESS, k_witness, cdiv(B, sblk), sblk, hog, s, B, N, n1, c.n_cst, in_dev, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v,
                    bd.ai1, bd.ao1, 1);
         LAUNCH(ctx, TAG_TRANSCRIPT, k_load_blindings, cdiv(B * m, 64), 64, s, B, m, ent_dev, bd.vb);
         if ((rc = commit_launch(ctx, B * m, bd.v, bd.vb, m, m, m, bd.pts, m + 8, s))) return rc;
         LAUNCH(ctx, TAG_ENCODE, k_encode_strided, cdiv(B * m, 64), 64, s, B * m, m, bd.pts, m + 8, bd.enc, encw, 0u);
-        LAUNCH_LDS(ctx, TAG_RNG, k_tr_open, cdiv(B, 64), 64, hog, s, B, m, n1, prefix, bd.enc, ent_dev, bd.vb, (u32*)ctx->raw.p, bd.tr, bd.rng);
+        LAUNCH_LDS(ctx, TAG_RNG, k_tr_open, cdiv(B, sblk), sblk, hog, s, B, m, n1, prefix, bd.enc, ent_dev, bd.vb, (u32*)ctx->raw.p, bd.tr, bd.rng);
         LAUNCH(ctx, TAG_RNG, k_reduce_draws, cdiv((u32)(B * n_draws), 128), 128, s, B, n1, (const u32*)ctx->raw.p, bd.ai1, bd.ao1, bd.s1);
         BBP_HIP_TRY(ctx, hipEventRecord(ctx->ev_open[par], s));
         ctx->ev_open_valid[par] = true;
@@ -1023,17 +1083,18 @@ static int32_t prove_heavy(bbp_ctx* ctx, const CircuitDev& c, const BatchDev& bd
         // switch to explicit folded generators: absorb round FOLD_ROUND-1, fold a, b, update g, h (no scalar rows), then one
         // composite-bucket pass materialises F_G[32], F_H[32]; the remaining rounds are small variable-base kernels
         DevBuf& vt = ctx->slice_vtab[slot];
-        if ((rc = dev_reserve(ctx, vt, (size_t)B * TAIL_BLK * 16 * sizeof(ge)))) return rc;
-        ge* vtab = static_cast<ge*>(vt.p);
+        if ((rc = dev_reserve(ctx, vt, (size_t)B * 2 * FOLD_CLS * TAIL_TAB * sizeof(ge)))) return rc;
+        ge* ftab = static_cast<ge*>(vt.p);
         LAUNCH(ctx, TAG_TRANSCRIPT, k_ipa_challenge, cdiv(B, 64), 64, s, B, tail_from - 1, m, bd.enc, bd.tr, bd.misc);
         LAUNCH(ctx, TAG_IPA_SCALARS, k_ipa_round, B, IPA_BLK, s, tail_from, m, bd.enc, bd.tr, bd.misc, bd.a, bd.b, bd.g, bd.h, (sc*)nullptr);
         if ((rc = fold_generators_launch(ctx, B, bd.g, bd.h, bd.fpts, s, slot))) return rc;
         LAUNCH(ctx, TAG_VARBASE, k_tail_init, cdiv(B * FOLD_CLS, 64), 64, s, B, bd.g, bd.h);
+        LAUNCH(ctx, TAG_VARBASE, k_tail_tables, cdiv(B * 2 * FOLD_CLS, 64), 64, s, B * 2 * FOLD_CLS, bd.fpts, ftab);
         for (u32 r = tail_from; r <= 11; r++) {
             const u32 n = 1024u >> (r - 1);
             if (r > tail_from)
                 LAUNCH(ctx, TAG_TRANSCRIPT, k_tail_step, cdiv(B, 64), 64, s, B, r - 1, 2 * n, m, bd.enc, bd.tr, bd.misc, bd.a, bd.b, bd.g, bd.h);
-            LAUNCH(ctx, TAG_VARBASE, k_tail_lr, B, TAIL_BLK, s, n, bd.misc, bd.a, bd.b, bd.g, bd.h, bd.fpts, ctx->gens, vtab, bd.lrpts);
+            LAUNCH(ctx, TAG_VARBASE, k_tail_lr, B, TAIL_BLK, s, n, bd.misc, bd.a, bd.b, bd.g, bd.h, ftab, ctx->btab, bd.lrpts);
             LAUNCH(ctx, TAG_ENCODE, k_encode_strided, cdiv(2 * B, 64), 64, s, 2 * B, 2u, bd.lrpts, 2u, bd.enc, encw, 8 * (m + 8 + 2 * (r - 1)));
         }
     }

@@ -103,6 +103,7 @@ extern "C" int32_t bbp_init(int32_t device, bbp_ctx** out) {
     BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_last, hipEventDisableTiming));
     if (const char* e = getenv("BBP_TAIL_ROUND")) ctx->tail_round = atoi(e) == bbp::FOLD_ROUND ? bbp::FOLD_ROUND : 12;
     if (const char* e = getenv("BBP_STAGGER")) ctx->stagger_mode = atoi(e);
+    if (const char* e = getenv("BBP_SERIAL_BLOCK")) ctx->serial_block = atoi(e) == 64 ? 64 : atoi(e) == 128 ? 128 : 256;
     if (const char* e = getenv("BBP_SERIAL_LDS")) ctx->serial_lds = atoi(e) < 0 ? 0 : atoi(e) > 160 * 1024 ? 160 * 1024 : atoi(e);
     if (const char* e = getenv("BBP_SLICES")) ctx->slices = atoi(e) < 1 ? 1 : atoi(e) > bbp_ctx::MAX_SLICES ? bbp_ctx::MAX_SLICES : atoi(e);
     for (int i = 0; i < 2; i++) {
@@ -138,6 +139,7 @@ extern "C" int32_t bbp_init(int32_t device, bbp_ctx** out) {
     BBP_HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_build_ptable, dim3((BBP_NUM_BASES * (MSM_POS / PT_CHUNK) + 63) / 64), dim3(64), 0, ctx->stream, ctx->gens, ctx->ptable);
     BBP_HIP_TRY(ctx, hipGetLastError());
+    if (int32_t rc = tail_btab_build(ctx)) return rc;
     hipLaunchKernelGGL(k_build_comb, dim3(2), dim3(64), 0, ctx->stream, ctx->gens, ctx->comb);
     BBP_HIP_TRY(ctx, hipGetLastError());
     BBP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -149,7 +151,7 @@ extern "C" void bbp_free(bbp_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    void* ptrs[] = {ctx->gens, ctx->ptable, ctx->slice_fold[0].p, ctx->slice_fold[1].p, ctx->slice_fold[2].p, ctx->slice_fold[3].p,
+    void* ptrs[] = {ctx->gens, ctx->ptable, ctx->btab, ctx->slice_fold[0].p, ctx->slice_fold[1].p, ctx->slice_fold[2].p, ctx->slice_fold[3].p,
                     ctx->slice_vtab[0].p, ctx->slice_vtab[1].p, ctx->slice_vtab[2].p, ctx->slice_vtab[3].p, ctx->comb, ctx->mimc_c, ctx->scal.p, ctx->idx.p, ctx->sorted.p, ctx->pts.p, ctx->enc.p, ctx->misc.p, ctx->batch.p, ctx->io_in.p, ctx->io_out.p, ctx->io_ent.p, ctx->raw.p, ctx->batch1.p, ctx->slice_sorted[1].p, ctx->slice_sorted[2].p, ctx->slice_sorted[3].p, ctx->slice_pts[1].p, ctx->slice_pts[2].p, ctx->slice_pts[3].p};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
