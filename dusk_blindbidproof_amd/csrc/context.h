@@ -45,7 +45,7 @@ struct bbp_ctx {
     static constexpr int MAX_SLICES = 4;   // heavy-stage slices of one batch, one stream each (slice 0 = caller's stream)
     hipStream_t lane[MAX_SLICES] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_join[MAX_SLICES] = {nullptr, nullptr, nullptr, nullptr}, ev_stagger[MAX_SLICES] = {nullptr, nullptr, nullptr, nullptr};
-    int slices = 2;
+    int slices = 3;
     int tail_round = bbp::FOLD_ROUND;  // first IPA round run on explicit folded generators (BBP_TAIL_ROUND=12 disables)
     int serial_lds = 160 * 1024;  // LDS the one-lane-per-proof opening kernels reserve to keep their CU to themselves (BBP_SERIAL_LDS, 0 = off)
     int serial_block = 64;        // threads per workgroup of those kernels: 256 = one serial wave per SIMD of the reserved CU (BBP_SERIAL_BLOCK)

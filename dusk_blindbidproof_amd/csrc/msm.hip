@@ -11,10 +11,10 @@
 // no doublings anywhere.  The hot loop is instruction-issue bound (measured: serving all rows from cache changes its time
 // by 7 %), so fewer additions and no unpacking are what count; the 134 MB of rows are HBM/MALL resident.
 //
-// One workgroup (2 wavefronts, 128 lanes) owns one MSM:
+// One workgroup owns one MSM, in two kernels (k_msm_sort: 256 thin lanes, k_msm_acc: 128 fat lanes):
 //   A. NAF digits of every scalar -> LDS histogram over bucket (|d| + 1) / 2
-//   B. exclusive scan -> bucket offsets (each lane owns 8 consecutive buckets)
-//   C. counting-sort scatter of (row index, sign) into the workgroup's HBM scratch slice
+//   B. exclusive scan -> bucket offsets
+//   C. counting-sort scatter of (row index, sign) into the MSM's HBM scratch slice; bucket end offsets to HBM
 //   D1. the sorted entry array is cut into 128 equal chunks, one per lane: mixed additions of table rows into bucket sums
 //   D2. running-sum fold over the lane's 8 buckets
 //   E. cross-lane fold (shuffles): W = sum_k k S_k and S = sum_k S_k; result = sum_k (2k - 1) S_k = 2 W - S
@@ -113,48 +113,64 @@ __device__ __forceinline__ ge ge_madd_row(const ge& p, const niels_row& q, bool 
 __device__ __noinline__ void ge_add_nc(ge& r, const ge& a, const ge& b) { r = ge_add(a, b); }
 __device__ __noinline__ void ge_dbl_nc(ge& r, const ge& a) { r = ge_dbl(a); }
 
-__global__ __launch_bounds__(MSM_T) __attribute__((amdgpu_waves_per_eu(BBP_MSM_WAVES, BBP_MSM_WAVES)))
-void k_msm(const u32* __restrict__ scalars, const u32* __restrict__ base_idx_sets, u32 n, u32 n_idx_sets, const niels_row* __restrict__ ptable,
-           u32* __restrict__ sorted_all, ge* __restrict__ bsum_all, ge* __restrict__ psum_all, ge* __restrict__ out) {
-    __shared__ u32 cursor[MSM_K + 1];  // histogram, then bucket start offsets, then (after the scatter) bucket end offsets
-    __shared__ u32 part[MSM_T];
-    __shared__ u32 xch[GE_WORDS];
+// ---------------------------------------------------------------------------------------------------------------
+// The MSM runs as TWO kernels.  The sort half (recoding, histogram, scan, scatter) is latency work -- LDS atomics with return,
+// 4-byte scattered stores -- and wants many thin waves; the accumulate half is issue-bound and wants two fat waves per SIMD.
+// Fused in one kernel the sort phases ran at the fat kernel's occupancy and took 21 % of its time.
+//
+// MODE 0: generic MSM -- scalars [n_msm][n], base rows from an index list, key = (|d| + 1) / 2                  (K = 1024)
+// MODE 1: generator fold for the IPA tail -- MSM 2p / 2p+1 = the G / H side of proof p, scalars g[p] / h[p], all 2048
+//         generators of the side, COMPOSITE key = class(i) * 128 + (|d| + 1) / 2 over width-9 NAF digits        (K = 4096)
+// Materialising folded generators (MODE 1): from round FOLD_ROUND on the IPA vectors are at most 32 long, and two 2049-term
+// MSMs per round cost far more than working with the 32 + 32 explicit folded generators F_G[i] = sum_{k = i mod 32} g[k] G[k]
+// (F_H likewise); one Pippenger pass per side computes all 32 sums, a running-sum fold per class (4 lanes x 32 keys) ends it.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int SORT_T = 256;
+template <int MODE> struct msm_geom;
+template <> struct msm_geom<0> { static constexpr int K = MSM_K, NAF = MSM_NAF, W = MSM_W; };
+template <> struct msm_geom<1> { static constexpr int K = FOLD_K, NAF = FOLD_NAF, W = FOLD_W; };
+
+template <int MODE>
+__global__ __launch_bounds__(SORT_T) void k_msm_sort(const u32* __restrict__ scal_a, const u32* __restrict__ aux, u32 n, u32 n_idx_sets,
+                                                      u32* __restrict__ sorted_all, u32* __restrict__ cursor_all) {
+    constexpr int K = msm_geom<MODE>::K, NAF = msm_geom<MODE>::NAF, W = msm_geom<MODE>::W, G = K / SORT_T;
+    __shared__ u32 cursor[K + 1];  // histogram, then bucket start offsets, then (after the scatter) bucket end offsets
+    __shared__ u32 part[SORT_T];
     const int tid = threadIdx.x;
     const size_t msm = blockIdx.x;
-    const u32* sbase = scalars + msm * (size_t)n * 8;
-    u32* sorted = sorted_all + msm * (size_t)n * MSM_W;
-    const u32* base_idx = base_idx_sets + (size_t)(blockIdx.x % n_idx_sets) * n;
-#ifdef BBP_MSM_PRIO
-    __builtin_amdgcn_s_setprio(BBP_MSM_PRIO);
-#endif
-    MSM_PROF_BEGIN();
+    const u32* sbase;
+    const u32* base_idx = nullptr;
+    u32 base0 = 0;
+    if (MODE == 0) {
+        sbase = scal_a + msm * (size_t)n * 8;
+        base_idx = aux + (size_t)(blockIdx.x % n_idx_sets) * n;
+    } else {
+        const u32 side = blockIdx.x & 1u;  // 0: G with g[], 1: H with h[]
+        sbase = (side ? aux : scal_a) + (msm >> 1) * (size_t)2048 * 8;
+        base0 = side ? BBP_BASE_H0 : BBP_BASE_G0;
+    }
+    u32* sorted = sorted_all + msm * (size_t)n * W;
+    auto key = [&](u32 i, u32 mag) -> u32 { return (MODE == 0 ? 0u : (i & (FOLD_CLS - 1)) * FOLD_M) + ((mag + 1) >> 1); };
 
-    for (int k = tid; k <= MSM_K; k += MSM_T) cursor[k] = 0;
+    for (int k = tid; k <= K; k += SORT_T) cursor[k] = 0;
     __syncthreads();
-
     // A. histogram
-    for (u32 i = tid; i < n; i += MSM_T) {
+    for (u32 i = tid; i < n; i += SORT_T) {
         const uint4* sp = reinterpret_cast<const uint4*>(sbase + (size_t)i * 8);
         uint4 lo = sp[0], hi = sp[1];
         const u32 s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        sc_for_each_naf_digit<MSM_NAF>(s, [&](u32, u32 mag, u32) { atomicAdd(&cursor[(mag + 1) >> 1], 1u); });
+        sc_for_each_naf_digit<NAF>(s, [&](u32, u32 mag, u32) { atomicAdd(&cursor[key(i, mag)], 1u); });
     }
     __syncthreads();
-    MSM_PROF_MARK(0);
-
     // B. offsets (in place: count -> exclusive prefix)
     {
-        u32 c[MSM_G], local = 0;
-#pragma unroll
-        for (int r = 1; r <= MSM_G; r++) {
-            c[r - 1] = cursor[tid * MSM_G + r];
-            local += c[r - 1];
-        }
+        u32 local = 0;
+        for (int r = 1; r <= G; r++) local += cursor[tid * G + r];
         part[tid] = local;
         __syncthreads();
         if (tid == 0) {
             u32 run = 0;
-            for (int t = 0; t < MSM_T; t++) {
+            for (int t = 0; t < SORT_T; t++) {
                 u32 v = part[t];
                 part[t] = run;
                 run += v;
@@ -162,42 +178,61 @@ void k_msm(const u32* __restrict__ scalars, const u32* __restrict__ base_idx_set
         }
         __syncthreads();
         u32 base = part[tid];
-#pragma unroll
-        for (int r = 1; r <= MSM_G; r++) {
-            cursor[tid * MSM_G + r] = base;
-            base += c[r - 1];
+        for (int r = 1; r <= G; r++) {
+            const u32 c = cursor[tid * G + r];
+            cursor[tid * G + r] = base;
+            base += c;
         }
     }
     __syncthreads();
-
     // C. scatter
-    for (u32 i = tid; i < n; i += MSM_T) {
+    for (u32 i = tid; i < n; i += SORT_T) {
         const uint4* sp = reinterpret_cast<const uint4*>(sbase + (size_t)i * 8);
         uint4 lo = sp[0], hi = sp[1];
         const u32 s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        const u32 tb = base_idx[i] * MSM_POS;
-        sc_for_each_naf_digit<MSM_NAF>(s, [&](u32 pos, u32 mag, u32 neg) {
-            u32 at = atomicAdd(&cursor[(mag + 1) >> 1], 1u);
+        const u32 tb = (MODE == 0 ? base_idx[i] : base0 + i) * MSM_POS;
+        sc_for_each_naf_digit<NAF>(s, [&](u32 pos, u32 mag, u32 neg) {
+            u32 at = atomicAdd(&cursor[key(i, mag)], 1u);
             sorted[at] = (tb + pos) | (neg << 31);
         });
     }
-    __threadfence_block();
+    __syncthreads();
+    u32* cur_out = cursor_all + msm * (size_t)(K + 1);
+    for (int k = tid; k <= K; k += SORT_T) cur_out[k] = k ? cursor[k] : 0u;  // cursor[k] = end offset of bucket k
+}
+
+template <int MODE>
+__global__ __launch_bounds__(MSM_T) __attribute__((amdgpu_waves_per_eu(BBP_MSM_WAVES, BBP_MSM_WAVES)))
+void k_msm_acc(const niels_row* __restrict__ ptable, const u32* __restrict__ sorted_all, const u32* __restrict__ cursor_all, u32 n,
+               ge* __restrict__ bsum_all, ge* __restrict__ psum_all, ge* __restrict__ out) {
+    constexpr int K = msm_geom<MODE>::K, W = msm_geom<MODE>::W, G = K / MSM_T;
+    __shared__ u32 cursor[K + 1];
+    __shared__ u32 xch[GE_WORDS];
+    const int tid = threadIdx.x;
+    const size_t msm = blockIdx.x;
+    const u32* sorted = sorted_all + msm * (size_t)n * W;
+#ifdef BBP_MSM_PRIO
+    __builtin_amdgcn_s_setprio(BBP_MSM_PRIO);
+#endif
+    MSM_PROF_BEGIN();
+    {
+        const u32* cur_in = cursor_all + msm * (size_t)(K + 1);
+        for (int k = tid; k <= K; k += MSM_T) cursor[k] = cur_in[k];
+    }
     __syncthreads();
     MSM_PROF_MARK(1);
 
     // D1. balanced bucket accumulation: the sorted entry array is cut into 128 EQUAL chunks, one per lane, whatever the
     //     bucket sizes are (a scalar repeated hundreds of times -- the padding rows of the first IPA round -- would
     //     otherwise serialise one lane).  A chunk that starts inside a bucket parks that leading partial sum in psum[lane];
-    //     every other bucket (or bucket head) it meets goes to bsum[bucket].  cursor[k] = end offset of bucket k now.
-    const u32 E = cursor[MSM_K];
-    if (tid == 0) cursor[0] = 0;
-    ge* bsum = bsum_all + msm * (size_t)MSM_K;           // [K] bucket k at index k-1
+    //     every other bucket (or bucket head) it meets goes to bsum[bucket].
+    const u32 E = cursor[K];
+    ge* bsum = bsum_all + msm * (size_t)K;               // [K] bucket k at index k-1
     ge* psum = psum_all + msm * (size_t)MSM_T;           // [T]
     const u32 c0 = (u32)(((u64)tid * E) / MSM_T), c1 = (u32)(((u64)(tid + 1) * E) / MSM_T);
-    __syncthreads();
     if (c0 < c1) {
         // bucket containing entry c0: smallest k with cursor[k] > c0
-        u32 lo = 1, hi = MSM_K;
+        u32 lo = 1, hi = K;
         while (lo < hi) {
             u32 mid = (lo + hi) >> 1;
             if (cursor[mid] > c0) hi = mid; else lo = mid + 1;
@@ -231,10 +266,10 @@ void k_msm(const u32* __restrict__ scalars, const u32* __restrict__ base_idx_set
     __syncthreads();
     MSM_PROF_MARK(3);
 
-    // D2. running-sum fold over this lane's 8 buckets (high to low), all lanes in lockstep
+    // D2. running-sum fold over this lane's G buckets (high to low), all lanes in lockstep
     ge running = ge_identity(), total = ge_identity();
-    for (int r = MSM_G; r >= 1; r--) {
-        const u32 k = tid * MSM_G + r;
+    for (int r = G; r >= 1; r--) {
+        const u32 k = tid * G + r;
         const u32 kend = cursor[k], kbeg = cursor[k - 1];
         if (kbeg != kend) {
             ge_add_nc(running, running, bsum[k - 1]);
@@ -249,205 +284,108 @@ void k_msm(const u32* __restrict__ scalars, const u32* __restrict__ base_idx_set
         }
         ge_add_nc(total, total, running);
     }
-
     MSM_PROF_MARK(4);
-    // E. cross-lane fold: W = sum_k k S_k = sum_t total_t + 8 * sum_{t>=1} suffix_t, suffix_t = sum_{u>=t} running_u
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int d = 1; d < 64; d <<= 1) {  // suffix scan inside each wavefront
-        ge other = ge_shfl_down(running, d);
-        if (lane + d < 64) ge_add_nc(running, running, other);
-    }
-    if (tid == 64) xch_put(xch, running);  // = sum over the upper wavefront
-    __syncthreads();
-    if (wave == 0) {
-        ge other = xch_get(xch);
-        ge_add_nc(running, running, other);
-    }
-    ge x = total;
-    if (tid >= 1) {
-        ge s = running;
-        for (int i = 0; i < MSM_LOG_G; i++) ge_dbl_nc(s, s);
-        ge_add_nc(x, x, s);
-    }
-    for (int d = 32; d >= 1; d >>= 1) {
-        ge other = ge_shfl_down(x, d);
-        if (lane < d) ge_add_nc(x, x, other);
-    }
-    __syncthreads();
-    if (tid == 64) xch_put(xch, x);
-    __syncthreads();
-    if (tid == 0) {
-        ge other = xch_get(xch);
-        ge_add_nc(x, x, other);
-        // bucket k holds the digit 2k - 1: result = 2 W - S, S = suffix_0 = lane 0's running
-        ge_dbl_nc(x, x);
-        other = ge_neg(running);
-        ge_add_nc(x, x, other);
-        out[msm] = x;
+
+    if (MODE == 0) {
+        // E. cross-lane fold: W = sum_k k S_k = sum_t total_t + G * sum_{t>=1} suffix_t, suffix_t = sum_{u>=t} running_u
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int d = 1; d < 64; d <<= 1) {  // suffix scan inside each wavefront
+            ge other = ge_shfl_down(running, d);
+            if (lane + d < 64) ge_add_nc(running, running, other);
+        }
+        if (tid == 64) xch_put(xch, running);  // = sum over the upper wavefront
+        __syncthreads();
+        if (wave == 0) {
+            ge other = xch_get(xch);
+            ge_add_nc(running, running, other);
+        }
+        ge x = total;
+        if (tid >= 1) {
+            ge s = running;
+            for (int i = 0; i < MSM_LOG_G; i++) ge_dbl_nc(s, s);
+            ge_add_nc(x, x, s);
+        }
+        for (int d = 32; d >= 1; d >>= 1) {
+            ge other = ge_shfl_down(x, d);
+            if (lane < d) ge_add_nc(x, x, other);
+        }
+        __syncthreads();
+        if (tid == 64) xch_put(xch, x);
+        __syncthreads();
+        if (tid == 0) {
+            ge other = xch_get(xch);
+            ge_add_nc(x, x, other);
+            // bucket k holds the digit 2k - 1: result = 2 W - S, S = suffix_0 = lane 0's running
+            ge_dbl_nc(x, x);
+            other = ge_neg(running);
+            ge_add_nc(x, x, other);
+            out[msm] = x;
+        }
+    } else {
+        // class (4 lanes x 32 keys): W = sum_q total_q + 32 * sum_{q>=1} suffix_q, S = suffix_0; result = 2 W - S
+        const int q = tid & 3;
+        ge suf = running;
+        for (int d = 1; d < 4; d++) {
+            ge other = ge_shfl_down(running, d);
+            if (q + d < 4) ge_add_nc(suf, suf, other);
+        }
+        ge x = total;
+        if (q >= 1) {
+            ge s32 = suf;
+            for (int i = 0; i < 5; i++) ge_dbl_nc(s32, s32);
+            ge_add_nc(x, x, s32);
+        }
+        ge acc4 = x;
+        for (int d = 1; d < 4; d++) {
+            ge other = ge_shfl_down(x, d);
+            if (q == 0) ge_add_nc(acc4, acc4, other);
+        }
+        if (q == 0) {
+            ge_dbl_nc(acc4, acc4);
+            ge other = ge_neg(suf);
+            ge_add_nc(acc4, acc4, other);
+            out[msm * FOLD_CLS + (tid >> 2)] = acc4;
+        }
     }
     MSM_PROF_MARK(5);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Materialising folded generators for the tail of the inner-product argument.
-//
-// From round FOLD_ROUND on, the IPA vectors are at most 32 long, and two 2049-term fixed-base MSMs per round cost far more
-// than working with the 32 + 32 explicit folded generators F_G[i] = sum_{k = i mod 32} g[k] G[k] (and F_H likewise).
-// This kernel computes those 32 sums of one side (G or H) of one proof in ONE Pippenger pass with COMPOSITE buckets
-// key = class(k) * 128 + (|digit| + 1) / 2 over width-9 NAF digits (odd, < 256) and the same row table: histogram /
-// counting sort / balanced accumulation as in k_msm, then a running-sum fold per class (4 lanes of 32 keys each).
-// ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(MSM_T) __attribute__((amdgpu_waves_per_eu(BBP_MSM_WAVES, BBP_MSM_WAVES)))
-void k_fold_generators(const sc* __restrict__ g_all, const sc* __restrict__ h_all, const niels_row* __restrict__ ptable,
-                       u32* __restrict__ sorted_all, ge* __restrict__ bsum_all, ge* __restrict__ psum_all, ge* __restrict__ out) {
-    __shared__ u32 cursor[FOLD_K + 1];
-    __shared__ u32 part[MSM_T];
-    const int tid = threadIdx.x;
-    const size_t msm = blockIdx.x;
-    const u32 side = blockIdx.x & 1u;  // 0: G with g[], 1: H with h[]
-    const u32* sbase = reinterpret_cast<const u32*>(side ? h_all : g_all) + (msm >> 1) * (size_t)2048 * 8;
-    const u32 base0 = side ? BBP_BASE_H0 : BBP_BASE_G0;
-    u32* sorted = sorted_all + msm * (size_t)2048 * FOLD_W;
-    constexpr int G2 = FOLD_K / MSM_T;  // 32 keys per lane = a quarter of one class
-
-    for (int k = tid; k <= FOLD_K; k += MSM_T) cursor[k] = 0;
-    __syncthreads();
-    for (u32 i = tid; i < 2048; i += MSM_T) {
-        const uint4* sp = reinterpret_cast<const uint4*>(sbase + (size_t)i * 8);
-        uint4 lo = sp[0], hi = sp[1];
-        const u32 s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        const u32 cls = (i & (FOLD_CLS - 1)) * FOLD_M;
-        sc_for_each_naf_digit<FOLD_NAF>(s, [&](u32, u32 mag, u32) { atomicAdd(&cursor[cls + ((mag + 1) >> 1)], 1u); });
-    }
-    __syncthreads();
-    {
-        u32 local = 0;
-        for (int r = 1; r <= G2; r++) local += cursor[tid * G2 + r];
-        part[tid] = local;
-        __syncthreads();
-        if (tid == 0) {
-            u32 run = 0;
-            for (int t = 0; t < MSM_T; t++) {
-                u32 v = part[t];
-                part[t] = run;
-                run += v;
-            }
-        }
-        __syncthreads();
-        u32 base = part[tid];
-        for (int r = 1; r <= G2; r++) {  // in place: count -> exclusive prefix
-            const u32 c = cursor[tid * G2 + r];
-            cursor[tid * G2 + r] = base;
-            base += c;
-        }
-    }
-    __syncthreads();
-    for (u32 i = tid; i < 2048; i += MSM_T) {
-        const uint4* sp = reinterpret_cast<const uint4*>(sbase + (size_t)i * 8);
-        uint4 lo = sp[0], hi = sp[1];
-        const u32 s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        const u32 cls = (i & (FOLD_CLS - 1)) * FOLD_M;
-        const u32 tb = (base0 + i) * MSM_POS;
-        sc_for_each_naf_digit<FOLD_NAF>(s, [&](u32 pos, u32 mag, u32 neg) {
-            u32 at = atomicAdd(&cursor[cls + ((mag + 1) >> 1)], 1u);
-            sorted[at] = (tb + pos) | (neg << 31);
-        });
-    }
-    __threadfence_block();
-    __syncthreads();
-
-    const u32 E = cursor[FOLD_K];
-    if (tid == 0) cursor[0] = 0;
-    ge* bsum = bsum_all + msm * (size_t)FOLD_K;
-    ge* psum = psum_all + msm * (size_t)MSM_T;
-    const u32 c0 = (u32)(((u64)tid * E) / MSM_T), c1 = (u32)(((u64)(tid + 1) * E) / MSM_T);
-    __syncthreads();
-    if (c0 < c1) {
-        u32 lo = 1, hi = FOLD_K;
-        while (lo < hi) {
-            u32 mid = (lo + hi) >> 1;
-            if (cursor[mid] > c0) hi = mid; else lo = mid + 1;
-        }
-        u32 k = lo, kend = cursor[k];
-        ge* dest = (cursor[k - 1] < c0) ? &psum[tid] : &bsum[k - 1];
-        ge acc = ge_identity();
-        u32 ent_cur = sorted[c0];
-        u32 ent_nxt = (c0 + 1 < c1) ? sorted[c0 + 1] : 0u;
-        niels_row row = load_row(ptable, ent_cur);
-        for (u32 e = c0; e < c1; e++) {
-            if (e == kend) {
-                *dest = acc;
-                acc = ge_identity();
-                do { k++; kend = cursor[k]; } while (kend == e);
-                dest = &bsum[k - 1];
-            }
-            const niels_row cur = row;
-            const bool neg = ent_cur >> 31;
-            ent_cur = ent_nxt;
-            if (e + 1 < c1) row = load_row(ptable, ent_cur);
-            if (e + 2 < c1) ent_nxt = sorted[e + 2];
-            acc = ge_madd_row(acc, cur, neg);
-        }
-        *dest = acc;
-    }
-    __threadfence_block();
-    __syncthreads();
-
-    // per-lane running-sum fold over 32 keys of one class: key = class*128 + m, m = 32 q + r
-    ge running = ge_identity(), total = ge_identity();
-    for (int r = G2; r >= 1; r--) {
-        const u32 k = tid * G2 + r;
-        const u32 kend = cursor[k], kbeg = cursor[k - 1];
-        if (kbeg != kend) {
-            ge_add_nc(running, running, bsum[k - 1]);
-            u32 t = (u32)(((u64)kbeg * MSM_T) / E);
-            for (; t < MSM_T; t++) {
-                const u32 ct = (u32)(((u64)t * E) / MSM_T);
-                if (ct >= kend) break;
-                const u32 ct1 = (u32)(((u64)(t + 1) * E) / MSM_T);
-                if (ct > kbeg && ct1 > ct) ge_add_nc(running, running, psum[t]);
-            }
-        }
-        ge_add_nc(total, total, running);
-    }
-    // class: W = sum_q total_q + 32 * sum_{q>=1} suffix_q and S = suffix_0 over the class's 4 lanes; result = 2 W - S
-    const int q = tid & 3;
-    ge suf = running;
-    for (int d = 1; d < 4; d++) {
-        ge other = ge_shfl_down(running, d);
-        if (q + d < 4) ge_add_nc(suf, suf, other);
-    }
-    ge x = total;
-    if (q >= 1) {
-        ge s32 = suf;
-        for (int i = 0; i < 5; i++) ge_dbl_nc(s32, s32);
-        ge_add_nc(x, x, s32);
-    }
-    ge acc4 = x;
-    for (int d = 1; d < 4; d++) {
-        ge other = ge_shfl_down(x, d);
-        if (q == 0) ge_add_nc(acc4, acc4, other);
-    }
-    if (q == 0) {
-        ge_dbl_nc(acc4, acc4);
-        ge other = ge_neg(suf);
-        ge_add_nc(acc4, acc4, other);
-        out[msm * FOLD_CLS + (tid >> 2)] = acc4;
-    }
+// scratch of one launch: sorted entries (n * W u32 per MSM) | bucket end offsets (K + 1 u32) | bucket sums (K points) |
+// chunk-leading partial sums (T points)
+struct MsmScratch {
+    u32 *sorted, *cursor;
+    ge *bsum, *psum;
+    size_t bytes;
+};
+static MsmScratch msm_scratch_layout(void* base, size_t n_msm, size_t n_terms, size_t W, size_t K) {
+    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+    MsmScratch m;
+    size_t o = 0;
+    m.sorted = reinterpret_cast<u32*>(static_cast<u8*>(base) + o);
+    o += up(n_msm * n_terms * W * sizeof(u32));
+    m.cursor = reinterpret_cast<u32*>(static_cast<u8*>(base) + o);
+    o += up(n_msm * (K + 1) * sizeof(u32));
+    m.bsum = reinterpret_cast<ge*>(static_cast<u8*>(base) + o);
+    o += n_msm * K * sizeof(ge);
+    m.psum = reinterpret_cast<ge*>(static_cast<u8*>(base) + o);
+    o += n_msm * MSM_T * sizeof(ge);
+    m.bytes = o;
+    return m;
 }
+size_t msm_scratch_bytes(uint32_t n_msm, uint32_t n_terms) { return msm_scratch_layout(nullptr, n_msm, n_terms, MSM_W, MSM_K).bytes; }
 
 int32_t fold_generators_launch(bbp_ctx* ctx, uint32_t n_proofs, const sc* g_dev, const sc* h_dev, ge* out_dev, hipStream_t stream,
                                int scratch_slot) {
     if (n_proofs == 0) return BBP_OK;
     const size_t n_msm = 2 * (size_t)n_proofs;
-    const size_t sorted_bytes = ((n_msm * 2048 * FOLD_W * sizeof(u32)) + 255) / 256 * 256;
     DevBuf& scratch = ctx->slice_fold[scratch_slot];
-    int32_t rc = dev_reserve(ctx, scratch, sorted_bytes + n_msm * (FOLD_K + MSM_T) * sizeof(ge));
+    int32_t rc = dev_reserve(ctx, scratch, msm_scratch_layout(nullptr, n_msm, 2048, FOLD_W, FOLD_K).bytes);
     if (rc) return rc;
-    ge* bsum = reinterpret_cast<ge*>(static_cast<u8*>(scratch.p) + sorted_bytes);
+    const MsmScratch m = msm_scratch_layout(scratch.p, n_msm, 2048, FOLD_W, FOLD_K);
     ScopedEvent ev(ctx, TAG_MSM, stream);
-    hipLaunchKernelGGL(k_fold_generators, dim3((u32)n_msm), dim3(MSM_T), 0, stream, g_dev, h_dev, ctx->ptable, (u32*)scratch.p, bsum,
-                       bsum + n_msm * FOLD_K, out_dev);
+    hipLaunchKernelGGL(k_msm_sort<1>, dim3((u32)n_msm), dim3(SORT_T), 0, stream, (const u32*)g_dev, (const u32*)h_dev, 2048u, 1u, m.sorted, m.cursor);
+    BBP_HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_msm_acc<1>, dim3((u32)n_msm), dim3(MSM_T), 0, stream, ctx->ptable, m.sorted, m.cursor, 2048u, m.bsum, m.psum, out_dev);
     BBP_HIP_TRY(ctx, hipGetLastError());
     return BBP_OK;
 }
@@ -463,12 +401,6 @@ __global__ __launch_bounds__(64) void k_encode(const ge* __restrict__ pts, u32 n
     o[1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
 
-// per MSM: sorted entries (n * W u32), bucket sums (K points), chunk-leading partial sums (T points)
-static size_t msm_sorted_bytes(uint32_t n_msm, uint32_t n_terms) { return (((size_t)n_msm * n_terms * MSM_W * sizeof(u32)) + 255) / 256 * 256; }
-size_t msm_scratch_bytes(uint32_t n_msm, uint32_t n_terms) {
-    return msm_sorted_bytes(n_msm, n_terms) + (size_t)n_msm * (MSM_K + MSM_T) * sizeof(ge);
-}
-
 int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* scalars_dev, const u32* base_idx_dev,
                    ge* out_points_dev, hipStream_t stream, uint32_t n_idx_sets, int scratch_slot) {
     if (n_msm == 0) return BBP_OK;
@@ -479,10 +411,11 @@ int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* sc
     DevBuf& scratch = scratch_slot ? ctx->slice_sorted[scratch_slot] : ctx->sorted;  // one scratch area per concurrently running stream
     int32_t rc = dev_reserve(ctx, scratch, msm_scratch_bytes(n_msm, n_terms));
     if (rc) return rc;
-    ge* bsum = reinterpret_cast<ge*>(static_cast<u8*>(scratch.p) + msm_sorted_bytes(n_msm, n_terms));
+    const MsmScratch m = msm_scratch_layout(scratch.p, n_msm, n_terms, MSM_W, MSM_K);
     ScopedEvent ev(ctx, TAG_MSM, stream);
-    hipLaunchKernelGGL(k_msm, dim3(n_msm), dim3(MSM_T), 0, stream, scalars_dev, base_idx_dev, n_terms, n_idx_sets, ctx->ptable,
-                       (u32*)scratch.p, bsum, bsum + (size_t)n_msm * MSM_K, out_points_dev);
+    hipLaunchKernelGGL(k_msm_sort<0>, dim3(n_msm), dim3(SORT_T), 0, stream, scalars_dev, base_idx_dev, n_terms, n_idx_sets, m.sorted, m.cursor);
+    BBP_HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_msm_acc<0>, dim3(n_msm), dim3(MSM_T), 0, stream, ctx->ptable, m.sorted, m.cursor, n_terms, m.bsum, m.psum, out_points_dev);
     BBP_HIP_TRY(ctx, hipGetLastError());
 #ifdef BBP_MSM_PROF
     static int launches = 0;
@@ -490,8 +423,8 @@ int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* sc
         unsigned long long h[8];
         (void)hipStreamSynchronize(stream);
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_msm_prof), sizeof h);
-        fprintf(stderr, "[msm prof, %d launches, 10ns ticks of lane 0 summed over WGs] A %llu BC %llu D1 %llu D1wait %llu D2 %llu E %llu\n", launches,
-                h[0], h[1], h[2], h[3], h[4], h[5]);
+        fprintf(stderr, "[msm prof, %d launches, 10ns ticks of lane 0 summed over WGs] load %llu D1 %llu D1wait %llu D2 %llu E %llu\n", launches,
+                h[1], h[2], h[3], h[4], h[5]);
     }
 #endif
     return BBP_OK;

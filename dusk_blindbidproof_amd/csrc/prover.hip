@@ -1001,7 +1001,7 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
         BBP_HIP_TRY(ctx, hipEventRecord(ctx->ev_open[par], s));
         ctx->ev_open_valid[par] = true;
     }
-    // HEAVY stage.  The batch is cut into slices (default 2, BBP_SLICES) that run the same kernel sequence on separate
+    // HEAVY stage.  The batch is cut into slices (default 3, BBP_SLICES) that run the same kernel sequence on separate
     // streams (slice 0 on the caller's): while one slice sits in a latency-bound step (the per-round transcript + scalar
     // inversion in k_ipa_round, the small encode / commit kernels) the other half's MSM keeps the CUs busy.
     const u32 slices = B >= 64u * (u32)ctx->slices ? (u32)ctx->slices : (B >= 128 ? 2u : 1u);
