@@ -118,6 +118,43 @@ BBP_HD fe fe_carry64(i64 (&h)[10]) {
     return r;
 }
 
+// Carry pass for columns that were PRE-BIASED: the multiply kernels start column k at 2^(bits_k - 1) instead of 0 (a constant
+// addend of the first multiply-add, so free), which turns the round-to-nearest carry c = (h + 2^(bits-1)) >> bits of the ten
+// first-time carries into a plain shift, and the signed remainder into (H & mask) - 2^(bits-1).  Same carry order and the same
+// results as fe_carry64; the two second-time carries (columns 4 and 0) work on small unbiased values.
+BBP_HD fe fe_carry64_prebiased(i64 (&h)[10]) {
+    fe r;
+    i64 c;
+#define BBP_PB(i, bits, nxt)                                                          \
+    c = h[i] >> (bits);                                                               \
+    h[nxt] += c;                                                                      \
+    r.v[i] = (i32)((u32)h[i] & ((1u << (bits)) - 1u)) - (i32)(1u << ((bits) - 1));
+    BBP_PB(0, 26, 1)
+    BBP_PB(4, 26, 5)
+    BBP_PB(1, 25, 2)
+    BBP_PB(5, 25, 6)
+    BBP_PB(2, 26, 3)
+    BBP_PB(6, 26, 7)
+    c = h[3] >> 25;  // column 3 -> column 4, which has been carried once already
+    r.v[3] = (i32)((u32)h[3] & ((1u << 25) - 1u)) - (i32)(1u << 24);
+    i64 x4 = (i64)r.v[4] + c;
+    BBP_PB(7, 25, 8)
+    c = (x4 + ((i64)1 << 25)) >> 26;
+    r.v[4] = (i32)(x4 - (c << 26));
+    r.v[5] += (i32)c;  // |c| < 2^12
+    BBP_PB(8, 26, 9)
+    c = h[9] >> 25;  // column 9 wraps to column 0 times 19
+    r.v[9] = (i32)((u32)h[9] & ((1u << 25) - 1u)) - (i32)(1u << 24);
+    i64 x0 = (i64)r.v[0] + 19 * c;
+    c = (x0 + ((i64)1 << 25)) >> 26;
+    r.v[0] = (i32)(x0 - (c << 26));
+    r.v[1] += (i32)c;  // |c| < 2^17
+#undef BBP_PB
+    return r;
+}
+
+#define BBP_FE_BIAS(k) ((i64)1 << (((k) & 1) ? 24 : 25))  // 2^(bits_k - 1): even columns hold 26 bits, odd ones 25
+
 // term f_i g_j lands in column (i+j) mod 10, times 19 when i+j >= 10 (2^255 = 19), times 2 when i and j are both odd
 BBP_HD fe fe_mul(const fe& f, const fe& g) {
     i32 g19[10], f2[10];
@@ -128,7 +165,7 @@ BBP_HD fe fe_mul(const fe& f, const fe& g) {
     }
     i64 h[10];
 #pragma unroll
-    for (int k = 0; k < 10; k++) h[k] = 0;
+    for (int k = 0; k < 10; k++) h[k] = BBP_FE_BIAS(k);
 #pragma unroll
     for (int i = 0; i < 10; i++) {
 #pragma unroll
@@ -139,11 +176,11 @@ BBP_HD fe fe_mul(const fe& f, const fe& g) {
             h[k % 10] += (i64)fi * gj;
         }
     }
-    return fe_carry64(h);
+    return fe_carry64_prebiased(h);
 }
 
 // dedicated squaring: 55 multiplies (off-diagonal terms once, doubled)
-BBP_HD fe fe_sq(const fe& f) {
+BBP_HD void fe_sq_columns(const fe& f, i64 (&h)[10]) {
     i32 f2[10], f19[10], f38[10];
 #pragma unroll
     for (int i = 0; i < 10; i++) {
@@ -151,9 +188,6 @@ BBP_HD fe fe_sq(const fe& f) {
         f19[i] = 19 * f.v[i];
         f38[i] = 38 * f.v[i];
     }
-    i64 h[10];
-#pragma unroll
-    for (int k = 0; k < 10; k++) h[k] = 0;
 #pragma unroll
     for (int i = 0; i < 10; i++) {
 #pragma unroll
@@ -173,7 +207,14 @@ BBP_HD fe fe_sq(const fe& f) {
             h[k % 10] += (i64)a * b;
         }
     }
-    return fe_carry64(h);
+}
+
+BBP_HD fe fe_sq(const fe& f) {
+    i64 h[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) h[k] = BBP_FE_BIAS(k);
+    fe_sq_columns(f, h);
+    return fe_carry64_prebiased(h);
 }
 
 // 2 * f^2, carried (point doubling needs it inside the multiply bounds)

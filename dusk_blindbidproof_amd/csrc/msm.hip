@@ -76,10 +76,13 @@ __device__ __forceinline__ niels_row load_row(const niels_row* __restrict__ tab,
     row &= BBP_EXP_ROWMASK;
 #endif
     const uint4* p = reinterpret_cast<const uint4*>(tab + row);
-    uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4], q5 = p[5], q6 = p[6], q7 = p[7];
-    niels_row r = {{(i32)q0.x, (i32)q0.y, (i32)q0.z, (i32)q0.w, (i32)q1.x, (i32)q1.y, (i32)q1.z, (i32)q1.w, (i32)q2.x, (i32)q2.y, (i32)q2.z,
-                    (i32)q2.w, (i32)q3.x, (i32)q3.y, (i32)q3.z, (i32)q3.w, (i32)q4.x, (i32)q4.y, (i32)q4.z, (i32)q4.w, (i32)q5.x, (i32)q5.y,
-                    (i32)q5.z, (i32)q5.w, (i32)q6.x, (i32)q6.y, (i32)q6.z, (i32)q6.w, (i32)q7.x, (i32)q7.y, (i32)q7.z, (i32)q7.w}};
+    uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4], q5 = p[5], q6 = p[6];
+    uint2 q7 = *reinterpret_cast<const uint2*>(p + 7);  // the two pad words are never loaded: they would cost two VGPRs
+    niels_row r;
+    const u32 w[30] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w,
+                       q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, q6.x, q6.y, q6.z, q6.w, q7.x, q7.y};
+#pragma unroll
+    for (int i = 0; i < 30; i++) r.v[i] = (i32)w[i];
     return r;
 }
 
