@@ -27,6 +27,12 @@ namespace bbp {
 #ifndef BBP_MSM_WAVES
 #define BBP_MSM_WAVES 2
 #endif
+// The upper bound only steers the scheduler's register appetite: with (2, 2) it spreads over ~240 VGPRs, with (2, 4) it stays
+// near 214 without spilling.  Two such waves leave ~80 VGPRs per SIMD lane free, enough for one thin wave of another stream's
+// kernel (transcript, encode, scalar kernels: <= 64 VGPRs) to run BESIDE the MSM instead of between MSMs.
+#ifndef BBP_MSM_WAVES_MAX
+#define BBP_MSM_WAVES_MAX 4
+#endif
 
 // -DBBP_MSM_PROF (experiments only): per-phase wall-clock (100 MHz) totals of lane 0 of every workgroup, printed every 16 launches
 #ifdef BBP_MSM_PROF
@@ -141,6 +147,7 @@ __global__ __launch_bounds__(SORT_T) void k_msm_sort(const u32* __restrict__ sca
     __shared__ u32 part[SORT_T];
     const int tid = threadIdx.x;
     const size_t msm = blockIdx.x;
+    __builtin_amdgcn_s_setprio(3);  // thin kernel: see BBP_THIN_PRIO in prover.hip
     const u32* sbase;
     const u32* base_idx = nullptr;
     u32 base0 = 0;
@@ -205,7 +212,7 @@ __global__ __launch_bounds__(SORT_T) void k_msm_sort(const u32* __restrict__ sca
 }
 
 template <int MODE>
-__global__ __launch_bounds__(MSM_T) __attribute__((amdgpu_waves_per_eu(BBP_MSM_WAVES, BBP_MSM_WAVES)))
+__global__ __launch_bounds__(MSM_T) __attribute__((amdgpu_waves_per_eu(BBP_MSM_WAVES, BBP_MSM_WAVES_MAX)))
 void k_msm_acc(const niels_row* __restrict__ ptable, const u32* __restrict__ sorted_all, const u32* __restrict__ cursor_all, u32 n,
                ge* __restrict__ bsum_all, ge* __restrict__ psum_all, ge* __restrict__ out) {
     constexpr int K = msm_geom<MODE>::K, W = msm_geom<MODE>::W, G = K / MSM_T;

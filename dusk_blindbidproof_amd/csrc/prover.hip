@@ -27,6 +27,12 @@
 
 namespace bbp {
 
+// Heavy-stage kernels other than the MSM accumulation are short and mostly latency-bound; when they share a SIMD with another
+// slice's two fat (older, issue-bound) accumulation waves they would crawl.  Raised wave priority lets them take the issue
+// slots they need -- a few percent of the SIMD -- and get out of the way.
+#define BBP_THIN_PRIO() __builtin_amdgcn_s_setprio(3)
+
+
 // ---------------------------------------------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------------------------------------------
@@ -190,6 +196,7 @@ int32_t commit_launch(bbp_ctx* ctx, u32 count, const sc* values, const sc* blind
 // encode `per_proof` points per proof from a strided point array into a strided encoding array
 __global__ void k_encode_strided(u32 count, u32 per_proof, const ge* __restrict__ pts, u32 pts_stride, u32* __restrict__ enc,
                                  u32 enc_stride_words, u32 enc_off_words) {
+    BBP_THIN_PRIO();
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= count) return;
     u32 p = t / per_proof, c = t % per_proof;
@@ -264,6 +271,7 @@ __global__ void k_load_blindings(u32 B, u32 m, const u8* __restrict__ entropy, s
 }
 
 __global__ void k_tr_yz(u32 B, u32 m, const u32* __restrict__ enc, merlin_transcript* __restrict__ tr, sc* __restrict__ misc) {
+    BBP_THIN_PRIO();
     u32 p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= B) return;
     merlin_transcript t = tr[p];
@@ -287,6 +295,7 @@ __global__ void k_tr_yz(u32 B, u32 m, const u32* __restrict__ enc, merlin_transc
 
 // out[p][e] = base[p]^e for e in [0, count): one lane per chunk of 32 exponents
 __global__ void k_powers(u32 B, u32 count, const sc* __restrict__ misc, int slot, sc* __restrict__ out, u32 out_stride) {
+    BBP_THIN_PRIO();
     const u32 chunks = (count + 31) / 32;
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B * chunks) return;
@@ -306,6 +315,7 @@ __global__ void k_powers(u32 B, u32 count, const sc* __restrict__ misc, int slot
 __global__ void k_flatten(u32 B, u32 n_tgt, u32 n_mul, u32 m, const u32* __restrict__ f_off, const u32* __restrict__ f_ent,
                           const sc* __restrict__ zpow, u32 zstride, sc* __restrict__ wl, sc* __restrict__ wr, sc* __restrict__ wo,
                           sc* __restrict__ wv, u32 wstride) {
+    BBP_THIN_PRIO();
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B * n_tgt) return;
     u32 p = t / n_tgt, k = t % n_tgt;
@@ -355,6 +365,7 @@ __global__ __launch_bounds__(POLY_BLK) void k_poly(u32 n1, const sc* __restrict_
                                                     u32 wstride, const sc* __restrict__ ypow, const sc* __restrict__ yipow,
                                                     sc* __restrict__ l1o, sc* __restrict__ r0o, sc* __restrict__ r1o, sc* __restrict__ r3o,
                                                     sc* __restrict__ misc) {
+    BBP_THIN_PRIO();
     __shared__ u32 lds[6 * 8 * POLY_BLK];
     const u32 p = blockIdx.x;
     const sc* aL = ai1 + (size_t)p * (1 + 2 * n1) + 1;
@@ -394,6 +405,7 @@ __global__ __launch_bounds__(POLY_BLK) void k_poly(u32 n1, const sc* __restrict_
 }
 
 __global__ void k_tr_tblind(u32 B, merlin_transcript* __restrict__ rng, sc* __restrict__ misc) {
+    BBP_THIN_PRIO();
     u32 p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= B) return;
     merlin_transcript r = rng[p];
@@ -408,6 +420,7 @@ __global__ void k_tr_tblind(u32 B, merlin_transcript* __restrict__ rng, sc* __re
 
 // T_k = t_k B + tb_k B~ for k in {1,3,4,5,6}: one lane per (proof, k)
 __global__ void k_commit_T(u32 B, const sc* __restrict__ misc, const niels_packed* __restrict__ comb, ge* __restrict__ pts, u32 pts_stride, u32 m) {
+    BBP_THIN_PRIO();
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B * 5) return;
     u32 p = t / 5, k = t % 5;
@@ -421,6 +434,7 @@ __global__ void k_commit_T(u32 B, const sc* __restrict__ misc, const niels_packe
 __global__ void k_tr_ux(u32 B, u32 m, u32 n1, const u32* __restrict__ enc, const sc* __restrict__ wv, const sc* __restrict__ vb,
                         const sc* __restrict__ ai1, const sc* __restrict__ ao1, const sc* __restrict__ s1,
                         merlin_transcript* __restrict__ tr, sc* __restrict__ misc) {
+    BBP_THIN_PRIO();
     u32 p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= B) return;
     merlin_transcript t = tr[p];
@@ -464,6 +478,7 @@ __global__ void k_tr_ux(u32 B, u32 m, u32 n1, const u32* __restrict__ enc, const
 __global__ void k_lrvec(u32 B, u32 n1, const sc* __restrict__ l1, const sc* __restrict__ r0, const sc* __restrict__ r1, const sc* __restrict__ r3,
                         const sc* __restrict__ ao1, const sc* __restrict__ s1, const sc* __restrict__ ypow, const sc* __restrict__ yipow,
                         const sc* __restrict__ misc, sc* __restrict__ a, sc* __restrict__ b, sc* __restrict__ g, sc* __restrict__ h) {
+    BBP_THIN_PRIO();
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B * 2048) return;
     u32 p = t >> 11, i = t & 2047;
@@ -490,6 +505,7 @@ __global__ void k_lrvec(u32 B, u32 n1, const sc* __restrict__ l1, const sc* __re
 // Fiat-Shamir step between IPA rounds: absorb L_j, R_j (j = prev_round), draw u_j, invert it.  One lane per proof.
 __global__ void k_ipa_challenge(u32 B, u32 prev_round, u32 m, const u32* __restrict__ enc, merlin_transcript* __restrict__ tr,
                                 sc* __restrict__ misc) {
+    BBP_THIN_PRIO();
     u32 p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= B) return;
     merlin_transcript t = tr[p];
@@ -510,6 +526,7 @@ constexpr int IPA_BLK = 256;
 __global__ __launch_bounds__(IPA_BLK) void k_ipa_round(u32 round, u32 m, const u32* __restrict__ enc, merlin_transcript* __restrict__ tr,
                                                         sc* __restrict__ misc, sc* __restrict__ a_all, sc* __restrict__ b_all,
                                                         sc* __restrict__ g_all, sc* __restrict__ h_all, sc* __restrict__ lr_all) {
+    BBP_THIN_PRIO();
     __shared__ u32 lds[2 * 8 * IPA_BLK];
     __shared__ u32 bc[16];
     const u32 p = blockIdx.x, tid = threadIdx.x;
@@ -634,6 +651,7 @@ __device__ ge ge_double_scalarmul(const sc& s1, const ge& P1, const sc& s2, cons
 // 252 + 64 + 7, and the tables of the 64 materialised generators are built once and used by all five tail rounds.
 constexpr int TAIL_TAB = 32;
 __global__ void k_tail_tables(u32 count, const ge* __restrict__ pts, ge* __restrict__ tab) {
+    BBP_THIN_PRIO();
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= count) return;
     ge P = pts[t];
@@ -684,6 +702,7 @@ __device__ ge ge_scalarmul_pieces(const sc& s, const ge* __restrict__ T) {
 // the first 32 slots of bd.g / bd.h once the big factor vectors have been consumed by k_fold_generators) and multiplies
 // them into the term scalars.  Every tail round is then ONE launch of 2 x 33 independent scalar multiplications per proof.
 __global__ void k_tail_init(u32 B, sc* __restrict__ g_all, sc* __restrict__ h_all) {
+    BBP_THIN_PRIO();
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B * FOLD_CLS) return;
     const u32 p = t / FOLD_CLS, k = t % FOLD_CLS;
@@ -694,6 +713,7 @@ __global__ void k_tail_init(u32 B, sc* __restrict__ g_all, sc* __restrict__ h_al
 // between tail rounds (one lane per proof): absorb L, R of `prev_round`, draw u, invert; fold a, b to length n2 and update gg, hh
 __global__ void k_tail_step(u32 B, u32 prev_round, u32 n2, u32 m, const u32* __restrict__ enc, merlin_transcript* __restrict__ tr,
                             sc* __restrict__ misc, sc* __restrict__ a_all, sc* __restrict__ b_all, sc* __restrict__ g_all, sc* __restrict__ h_all) {
+    BBP_THIN_PRIO();
     u32 p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= B) return;
     merlin_transcript t = tr[p];
@@ -723,6 +743,7 @@ constexpr int TAIL_BLK = 128;
 __global__ __launch_bounds__(TAIL_BLK) void k_tail_lr(u32 n, const sc* __restrict__ misc, const sc* __restrict__ a_all, const sc* __restrict__ b_all,
                                                        const sc* __restrict__ g_all, const sc* __restrict__ h_all, const ge* __restrict__ ftab,
                                                        const ge* __restrict__ btab, ge* __restrict__ lrpts) {
+    BBP_THIN_PRIO();
     __shared__ u32 stage[GE_WORDS * TAIL_BLK];
     const u32 p = blockIdx.x, tid = threadIdx.x;
     const u32 side = tid >> 6, j = tid & 63;  // 64 slots per side, 33 used
@@ -772,6 +793,7 @@ __global__ __launch_bounds__(TAIL_BLK) void k_tail_lr(u32 n, const sc* __restric
 
 __global__ void k_ipa_final(u32 B, u32 m, const u32* __restrict__ enc, merlin_transcript* __restrict__ tr, sc* __restrict__ misc,
                             const sc* __restrict__ a_all, const sc* __restrict__ b_all) {
+    BBP_THIN_PRIO();
     u32 p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= B) return;
     merlin_transcript t = tr[p];
@@ -789,6 +811,7 @@ __global__ void k_ipa_final(u32 B, u32 m, const u32* __restrict__ enc, merlin_tr
 
 // record = R1CSProof::to_bytes (1-phase compact form, A.8) || V[0..4) || V[4..m)
 __global__ void k_assemble(u32 B, u32 m, const u32* __restrict__ enc, const sc* __restrict__ misc, u8* __restrict__ out) {
+    BBP_THIN_PRIO();
     u32 p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= B) return;
     const u32* e = enc + (size_t)p * enc_stride_words(m);
