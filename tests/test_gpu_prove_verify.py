@@ -263,3 +263,39 @@ def test_calls_from_different_streams_are_serialised(ctx, oc, bbp):
     for (out, _), status in zip(outs, sts):
         assert bytes(out.cpu().numpy().tobytes()) == ref
         assert status.cpu().tolist() == [0] * B
+
+
+@pytest.mark.parametrize("knobs", [
+    {"BBP_TAIL_ROUND": "12"},                                   # all 11 IPA rounds on the fixed-base MSM kernels (no folded-generator tail)
+    {"BBP_SLICES": "1", "BBP_SERIAL_LDS": "0"},                 # one heavy-stage stream, serial kernels not fenced off
+    {"BBP_SLICES": "4", "BBP_SERIAL_BLOCK": "256"},             # four slices (two of them share a hardware queue by default)
+    {"BBP_SLICES": "2", "BBP_STAGGER": "1"},
+])
+def test_engine_schedules_give_identical_bytes(bbp, oc, knobs):
+    """The scheduling knobs (slices, tail round, serial-kernel fencing, stagger) change WHEN and HOW work runs, never the bytes:
+    every variant must reproduce the C oracle's records under the same entropy, for a batch that spans every slice."""
+    import os
+    old = {k: os.environ.get(k) for k in knobs}
+    os.environ.update(knobs)
+    try:
+        c2 = bbp.Context(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    try:
+        B, N = 261, 3
+        ins, ents, vins = _synth_batch(c2, B, N, seed=4242)
+        rs_ = bbp.record_size(N)
+        for _ in range(2):  # second call runs on the other buffer parity, overlapped with the first
+            out, st = c2.prove_batch(B, N, b"".join(ins), b"".join(ents))
+            assert st == [0] * B
+        cout, cst = oc.prove_many(b"".join(ins), b"".join(ents), B, N, threads=8)
+        assert cst == [0] * B
+        assert out == cout
+        vin = b"".join(out[i * rs_:(i + 1) * rs_] + v[0] + v[1] + v[2] + v[3] for i, v in enumerate(vins))
+        assert c2.verify_batch(B, N, vin) == [0] * B
+    finally:
+        c2.close()
