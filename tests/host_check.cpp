@@ -74,6 +74,7 @@ void hc_sc_op(int op, const uint8_t* a, const uint8_t* b32, uint8_t* out32) {
             case 1: r = sc_sub(x, y); break;
             case 2: r = sc_mul(x, y); break;
             case 3: r = sc_invert(x); break;
+            case 7: r = sc_invert_fermat(x); break;
             default: r = sc_neg(x); break;
         }
     }

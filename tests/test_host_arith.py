@@ -72,7 +72,13 @@ def test_scalar_ops(lib):
         assert sc_op(6, b32(a)) == (-a) % L
     for a in svals[:30]:
         if a:
-            assert sc_op(3, b32(a)) == pow(a, L - 2, L)
+            assert sc_op(7, b32(a)) == pow(a, L - 2, L)   # Fermat ladder (kept as a cross-check)
+    # safegcd inversion: edge values, powers of two and their neighbours, small values, dense random sample; 0 -> 0
+    inv_vals = svals + [3, 4, 5, 2**30 - 1, 2**30, 2**30 + 1, 2**60, 2**90 - 1, L - 3, (L + 1) // 2, (L - 1) // 2, 2**251, 2**252 + 1]
+    inv_vals += [2**k for k in range(0, 252, 7)] + [L - 2**k for k in range(1, 252, 11)] + [rnd.randrange(L) for _ in range(3000)]
+    inv_vals += [rnd.getrandbits(rnd.randrange(1, 252)) for _ in range(500)]
+    for a in inv_vals:
+        assert sc_op(3, b32(a)) == (pow(a, L - 2, L) if a else 0), hex(a)
     for w in [0, 2**512 - 1, 2**256 - 1, 2**256, L, L << 256] + [rnd.getrandbits(512) for _ in range(200)]:
         assert sc_op(4, w.to_bytes(64, "little")) == w % L
     for w in [2**256 - 1, 2**255, 2**255 - 1, L, L + 1, 15 * L + 7] + [rnd.getrandbits(256) for _ in range(100)]:
