@@ -710,44 +710,50 @@ __global__ void k_tail_init(u32 B, sc* __restrict__ g_all, sc* __restrict__ h_al
     st_sc(&h_all[(size_t)p * 2048 + k], sc_one());
 }
 
-// between tail rounds (one lane per proof): absorb L, R of `prev_round`, draw u, invert; fold a, b to length n2 and update gg, hh
-__global__ void k_tail_step(u32 B, u32 prev_round, u32 n2, u32 m, const u32* __restrict__ enc, merlin_transcript* __restrict__ tr,
-                            sc* __restrict__ misc, sc* __restrict__ a_all, sc* __restrict__ b_all, sc* __restrict__ g_all, sc* __restrict__ h_all) {
-    BBP_THIN_PRIO();
-    u32 p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= B) return;
-    merlin_transcript t = tr[p];
-    const u32* e = enc + (size_t)p * enc_stride_words(m) + 8 * (m + 8) + 16 * (prev_round - 1);
-    tr_append_words(t, LBL("L"), e);
-    tr_append_words(t, LBL("R"), e + 8);
-    const sc u = tr_challenge_sc(t, LBL("u"));
-    const sc ui = sc_invert(u);
-    tr[p] = t;
-    sc *a = a_all + (size_t)p * 2048, *b = b_all + (size_t)p * 2048, *gg = g_all + (size_t)p * 2048, *hh = h_all + (size_t)p * 2048;
-    for (u32 i = 0; i < n2; i++) {
-        sc alo = ld_sc(&a[i]), ahi = ld_sc(&a[n2 + i]), blo = ld_sc(&b[i]), bhi = ld_sc(&b[n2 + i]);
-        st_sc(&a[i], sc_add(sc_mul(alo, u), sc_mul(ui, ahi)));
-        st_sc(&b[i], sc_add(sc_mul(blo, ui), sc_mul(u, bhi)));
-    }
-    for (u32 k = 0; k < FOLD_CLS; k++) {
-        const bool hi = (k & (2 * n2 - 1)) >= n2;
-        st_sc(&gg[k], sc_mul(ld_sc(&gg[k]), hi ? u : ui));
-        st_sc(&hh[k], sc_mul(ld_sc(&hh[k]), hi ? ui : u));
-    }
-}
-
 // L and R of a tail round (half length n <= 16) over the 32 + 32 materialised generators: one lane per (side, term), 33 terms a side.
 //   L = sum_{hi k} a[io] gg[k] F_G[k] + sum_{lo k} b[n+io] hh[k] F_H[k] + c_L w B      (k = blk 2n + {0, n} + io, rank = blk n + io)
 //   R = sum_{lo k} a[n+io] gg[k] F_G[k] + sum_{hi k} b[io] hh[k] F_H[k] + c_R w B
+// With `prev_round` != 0 the block first finishes the previous round: lane 0 absorbs L, R of that round, draws u and inverts it
+// (the other lanes wait), then the block folds a, b to length 2n and updates gg, hh in parallel.
 constexpr int TAIL_BLK = 128;
-__global__ __launch_bounds__(TAIL_BLK) void k_tail_lr(u32 n, const sc* __restrict__ misc, const sc* __restrict__ a_all, const sc* __restrict__ b_all,
-                                                       const sc* __restrict__ g_all, const sc* __restrict__ h_all, const ge* __restrict__ ftab,
+__global__ __launch_bounds__(TAIL_BLK) void k_tail_lr(u32 n, u32 prev_round, u32 m, const u32* __restrict__ enc, merlin_transcript* __restrict__ tr,
+                                                       const sc* __restrict__ misc, sc* __restrict__ a_all, sc* __restrict__ b_all,
+                                                       sc* __restrict__ g_all, sc* __restrict__ h_all, const ge* __restrict__ ftab,
                                                        const ge* __restrict__ btab, ge* __restrict__ lrpts) {
     BBP_THIN_PRIO();
     __shared__ u32 stage[GE_WORDS * TAIL_BLK];
     const u32 p = blockIdx.x, tid = threadIdx.x;
     const u32 side = tid >> 6, j = tid & 63;  // 64 slots per side, 33 used
-    const sc *a = a_all + (size_t)p * 2048, *b = b_all + (size_t)p * 2048, *gg = g_all + (size_t)p * 2048, *hh = h_all + (size_t)p * 2048;
+    sc *a = a_all + (size_t)p * 2048, *b = b_all + (size_t)p * 2048, *gg = g_all + (size_t)p * 2048, *hh = h_all + (size_t)p * 2048;
+    if (prev_round) {
+        sc* uu = reinterpret_cast<sc*>(stage);  // u, 1/u
+        if (tid == 0) {
+            merlin_transcript t = tr[p];
+            const u32* e = enc + (size_t)p * enc_stride_words(m) + 8 * (m + 8) + 16 * (prev_round - 1);
+            tr_append_words(t, LBL("L"), e);
+            tr_append_words(t, LBL("R"), e + 8);
+            const sc u = tr_challenge_sc(t, LBL("u"));
+            uu[0] = u;
+            uu[1] = sc_invert(u);
+            tr[p] = t;
+        }
+        __syncthreads();
+        const sc u = uu[0], ui = uu[1];
+        const u32 n2 = 2 * n;
+        if (tid < n2) {
+            st_sc(&a[tid], sc_add(sc_mul(ld_sc(&a[tid]), u), sc_mul(ui, ld_sc(&a[n2 + tid]))));
+        } else if (tid < 2 * n2) {
+            const u32 i = tid - n2;
+            st_sc(&b[i], sc_add(sc_mul(ld_sc(&b[i]), ui), sc_mul(u, ld_sc(&b[n2 + i]))));
+        } else if (tid >= 64) {
+            const u32 k = tid & 31;
+            const bool hi = (k & (2 * n2 - 1)) >= n2;
+            if (tid < 96) st_sc(&gg[k], sc_mul(ld_sc(&gg[k]), hi ? u : ui));
+            else st_sc(&hh[k], sc_mul(ld_sc(&hh[k]), hi ? ui : u));
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
     const ge *FG = ftab + (size_t)p * 2 * FOLD_CLS * TAIL_TAB, *FH = FG + (size_t)FOLD_CLS * TAIL_TAB;  // tables of F_G[32], F_H[32]
     constexpr u32 HALF = FOLD_CLS / 2;  // 16 G-terms and 16 H-terms per side
     ge q = ge_identity();
@@ -1115,9 +1121,8 @@ static int32_t prove_heavy(bbp_ctx* ctx, const CircuitDev& c, const BatchDev& bd
         LAUNCH(ctx, TAG_VARBASE, k_tail_tables, cdiv(B * 2 * FOLD_CLS, 64), 64, s, B * 2 * FOLD_CLS, bd.fpts, ftab);
         for (u32 r = tail_from; r <= 11; r++) {
             const u32 n = 1024u >> (r - 1);
-            if (r > tail_from)
-                LAUNCH(ctx, TAG_TRANSCRIPT, k_tail_step, cdiv(B, 64), 64, s, B, r - 1, 2 * n, m, bd.enc, bd.tr, bd.misc, bd.a, bd.b, bd.g, bd.h);
-            LAUNCH(ctx, TAG_VARBASE, k_tail_lr, B, TAIL_BLK, s, n, bd.misc, bd.a, bd.b, bd.g, bd.h, ftab, ctx->btab, bd.lrpts);
+            LAUNCH(ctx, TAG_VARBASE, k_tail_lr, B, TAIL_BLK, s, n, r > tail_from ? r - 1 : 0u, m, bd.enc, bd.tr, bd.misc, bd.a, bd.b, bd.g, bd.h, ftab,
+                   ctx->btab, bd.lrpts);
             LAUNCH(ctx, TAG_ENCODE, k_encode_strided, cdiv(2 * B, 64), 64, s, 2 * B, 2u, bd.lrpts, 2u, bd.enc, encw, 8 * (m + 8 + 2 * (r - 1)));
         }
     }
