@@ -4,8 +4,8 @@ import os
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-TAG_NAMES = {1: "k_msm", 2: "k_encode", 3: "k_witness", 4: "k_tr_open(rng)", 5: "k_poly/powers/flatten", 6: "k_ipa_round", 7: "k_commit",
-             8: "k_transcript", 9: "k_vscalars", 10: "k_varbase"}
+TAG_NAMES = {1: "k_msm_acc", 11: "k_msm_sort", 2: "k_encode", 3: "k_witness", 4: "k_tr_open(rng)", 5: "k_poly/powers/flatten", 6: "k_ipa_round", 7: "k_commit",
+             8: "k_transcript", 9: "k_vscalars", 10: "k_varbase/tail"}
 L = 2**252 + 27742317777372353535851937790883648493
 
 
@@ -74,7 +74,7 @@ def _kernel_table(timings):
 
 
 # average non-zero digits per scalar of the engine's recodings (tests/test_host_arith.py::test_naf_recoding measures them):
-# width-12 NAF in k_msm, width-9 NAF in k_fold_generators; one digit = one table-row addition
+# width-12 NAF in the <0> MSM kernels, width-9 NAF in the <1> (generator fold) instances; one digit = one table-row addition
 NAF12_DIGITS, NAF9_DIGITS = 19.85, 25.66
 
 
@@ -85,7 +85,7 @@ MEASURED_TRAFFIC_PROVE_1024_8 = (2 * 2755095 + 1732449) * 1024  # profiles/r01_r
 
 class _Base:
     dominant_tag = 1
-    dominant_kernel = "k_msm"
+    dominant_kernel = "k_msm_acc"
     measured_traffic_bytes = None
 
     def extra_report(self, timings):

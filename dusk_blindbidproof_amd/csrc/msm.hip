@@ -392,9 +392,12 @@ int32_t fold_generators_launch(bbp_ctx* ctx, uint32_t n_proofs, const sc* g_dev,
     int32_t rc = dev_reserve(ctx, scratch, msm_scratch_layout(nullptr, n_msm, 2048, FOLD_W, FOLD_K).bytes);
     if (rc) return rc;
     const MsmScratch m = msm_scratch_layout(scratch.p, n_msm, 2048, FOLD_W, FOLD_K);
+    {
+        ScopedEvent ev(ctx, TAG_MSM_SORT, stream);
+        hipLaunchKernelGGL(k_msm_sort<1>, dim3((u32)n_msm), dim3(SORT_T), 0, stream, (const u32*)g_dev, (const u32*)h_dev, 2048u, 1u, m.sorted, m.cursor);
+        BBP_HIP_TRY(ctx, hipGetLastError());
+    }
     ScopedEvent ev(ctx, TAG_MSM, stream);
-    hipLaunchKernelGGL(k_msm_sort<1>, dim3((u32)n_msm), dim3(SORT_T), 0, stream, (const u32*)g_dev, (const u32*)h_dev, 2048u, 1u, m.sorted, m.cursor);
-    BBP_HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_msm_acc<1>, dim3((u32)n_msm), dim3(MSM_T), 0, stream, ctx->ptable, m.sorted, m.cursor, 2048u, m.bsum, m.psum, out_dev);
     BBP_HIP_TRY(ctx, hipGetLastError());
     return BBP_OK;
@@ -422,9 +425,12 @@ int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* sc
     int32_t rc = dev_reserve(ctx, scratch, msm_scratch_bytes(n_msm, n_terms));
     if (rc) return rc;
     const MsmScratch m = msm_scratch_layout(scratch.p, n_msm, n_terms, MSM_W, MSM_K);
+    {
+        ScopedEvent ev(ctx, TAG_MSM_SORT, stream);
+        hipLaunchKernelGGL(k_msm_sort<0>, dim3(n_msm), dim3(SORT_T), 0, stream, scalars_dev, base_idx_dev, n_terms, n_idx_sets, m.sorted, m.cursor);
+        BBP_HIP_TRY(ctx, hipGetLastError());
+    }
     ScopedEvent ev(ctx, TAG_MSM, stream);
-    hipLaunchKernelGGL(k_msm_sort<0>, dim3(n_msm), dim3(SORT_T), 0, stream, scalars_dev, base_idx_dev, n_terms, n_idx_sets, m.sorted, m.cursor);
-    BBP_HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_msm_acc<0>, dim3(n_msm), dim3(MSM_T), 0, stream, ctx->ptable, m.sorted, m.cursor, n_terms, m.bsum, m.psum, out_points_dev);
     BBP_HIP_TRY(ctx, hipGetLastError());
 #ifdef BBP_MSM_PROF
