@@ -6,6 +6,8 @@
 //   kind 2: fe_sq chains                                                          -> field squarings/s
 //   kind 3: ge_madd chain (register-resident cached point, no memory)            -> mixed additions/s
 //   kind 4: sc_montmul chains                                                     -> Montgomery products mod l /s
+//   kind 5: ge_madd chain whose cached point is opaque to the compiler each iteration (as a freshly gathered table row
+//           is: 19 * limb precomputations cannot be hoisted)                       -> mixed additions/s
 #include <stdlib.h>
 
 #include "context.h"
@@ -50,6 +52,23 @@ __global__ __launch_bounds__(256) void k_ubench(int kind, u32 iters, u32* __rest
         n.xy2d = fe_sqrt_m1();
         for (u32 i = 0; i < iters; i++) p = ge_madd(p, n);
         acc = (u32)(p.X.v[0] ^ p.T.v[2]);
+    } else if (kind == 5) {
+        ge p = ge_basepoint();
+        p.X.v[0] ^= (i32)(t & 0xffff);
+        ge_niels n;
+        n.ypx = fe_d();
+        n.ymx = fe_d2();
+        n.xy2d = fe_sqrt_m1();
+        for (u32 i = 0; i < iters; i++) {
+#pragma unroll
+            for (int k = 0; k < 10; k++) {
+                asm volatile("" : "+v"(n.ypx.v[k]));
+                asm volatile("" : "+v"(n.ymx.v[k]));
+                asm volatile("" : "+v"(n.xy2d.v[k]));
+            }
+            p = ge_madd(p, n);
+        }
+        acc = (u32)(p.X.v[0] ^ p.T.v[2]);
     } else {
         sc a = sc_rr(), b = sc_r();
         a.v[0] ^= (t & 0xff);
@@ -66,9 +85,9 @@ __global__ __launch_bounds__(256) void k_ubench(int kind, u32 iters, u32* __rest
 
 using namespace bbp;
 
-// Runs `blocks` x 256 lanes x `iters` iterations; *ops_per_sec = operations/s (ops per iteration per lane: 4,2,2,1,2).
+// Runs `blocks` x 256 lanes x `iters` iterations; *ops_per_sec = operations/s (ops per iteration per lane: 4,2,2,1,2,1).
 extern "C" int32_t bbp_ubench(bbp_ctx* ctx, int32_t kind, uint32_t blocks, uint32_t iters, double* ops_per_sec) {
-    if (!ctx || !ops_per_sec || kind < 0 || kind > 4 || blocks == 0) return BBP_ERR_BAD_ARG;
+    if (!ctx || !ops_per_sec || kind < 0 || kind > 5 || blocks == 0) return BBP_ERR_BAD_ARG;
     BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
     int32_t rc = dev_reserve(ctx, ctx->misc, (size_t)blocks * 256 * 4);
     if (rc) return rc;
@@ -77,6 +96,7 @@ extern "C" int32_t bbp_ubench(bbp_ctx* ctx, int32_t kind, uint32_t blocks, uint3
     BBP_HIP_TRY(ctx, hipEventCreate(&b));
     const char* lds_env = getenv("BBP_UBENCH_LDS");
     const unsigned lds = lds_env ? (unsigned)atoi(lds_env) : 0u;
+    if (lds > 64 * 1024) BBP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ubench, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_ubench, dim3(blocks), dim3(256), lds, ctx->stream, kind, iters / 8 + 1, (u32*)ctx->misc.p);  // warm-up
     BBP_HIP_TRY(ctx, hipEventRecord(a, ctx->stream));
     hipLaunchKernelGGL(k_ubench, dim3(blocks), dim3(256), lds, ctx->stream, kind, iters, (u32*)ctx->misc.p);
@@ -86,7 +106,7 @@ extern "C" int32_t bbp_ubench(bbp_ctx* ctx, int32_t kind, uint32_t blocks, uint3
     BBP_HIP_TRY(ctx, hipEventElapsedTime(&ms, a, b));
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
-    const double per_iter[5] = {4, 2, 2, 1, 2};
+    const double per_iter[6] = {4, 2, 2, 1, 2, 1};
     *ops_per_sec = per_iter[kind] * (double)blocks * 256.0 * (double)iters / (ms * 1e-3);
     return BBP_OK;
 }

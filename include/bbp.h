@@ -114,7 +114,8 @@ int32_t bbp_verify_batch_dev(bbp_ctx* ctx, uint32_t B, uint32_t N, const void* i
 int32_t bbp_debug_challenges(bbp_ctx* ctx, uint32_t B, uint32_t N, uint32_t proof, uint8_t* out32x32);
 
 /* Integer-ALU roofline microbenchmarks (register-resident chains, no memory): kind 0 = v_mad_u64_u32, 1 = field multiply,
- * 2 = field square, 3 = mixed point addition, 4 = Montgomery product mod l.  *ops_per_sec receives operations per second. */
+ * 2 = field square, 3 = mixed point addition, 4 = Montgomery product mod l, 5 = mixed point addition with an operand the
+ * compiler cannot hoist (a gathered table row).  *ops_per_sec receives operations per second. */
 int32_t bbp_ubench(bbp_ctx* ctx, int32_t kind, uint32_t blocks, uint32_t iters, double* ops_per_sec);
 
 /* Per-kernel device timings: with profiling on, every kernel launch is bracketed by HIP events on its launch stream.
