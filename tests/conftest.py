@@ -25,6 +25,12 @@ def built():
 
 @pytest.fixture(scope="session")
 def bbp(built):
+    # torch ships its own copy of the HIP runtime; when libbbp_hip.so (linked against /opt/rocm) is loaded BEFORE torch and
+    # torch then initialises the GPU, the second runtime reports zero devices.  Load torch's first, whatever subset of tests runs.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     import dusk_blindbidproof_amd as m
     return m
 
