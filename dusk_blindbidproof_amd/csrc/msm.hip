@@ -240,6 +240,9 @@ void k_msm_acc(const niels_row* __restrict__ ptable, const u32* __restrict__ sor
     ge* bsum = bsum_all + msm * (size_t)K;               // [K] bucket k at index k-1
     ge* psum = psum_all + msm * (size_t)MSM_T;           // [T]
     const u32 c0 = (u32)(((u64)tid * E) / MSM_T), c1 = (u32)(((u64)(tid + 1) * E) / MSM_T);
+#ifdef BBP_MSM_PROF
+    const unsigned long long clk0 = clock64();
+#endif
     if (c0 < c1) {
         // bucket containing entry c0: smallest k with cursor[k] > c0
         u32 lo = 1, hi = K;
@@ -271,6 +274,9 @@ void k_msm_acc(const niels_row* __restrict__ ptable, const u32* __restrict__ sor
         }
         *dest = acc;
     }
+#ifdef BBP_MSM_PROF
+    if (tid == 0) atomicAdd(&g_msm_prof[6], clock64() - clk0);
+#endif
     MSM_PROF_MARK(2);
     __threadfence_block();
     __syncthreads();
@@ -439,8 +445,8 @@ int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* sc
         unsigned long long h[8];
         (void)hipStreamSynchronize(stream);
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_msm_prof), sizeof h);
-        fprintf(stderr, "[msm prof, %d launches, 10ns ticks of lane 0 summed over WGs] load %llu D1 %llu D1wait %llu D2 %llu E %llu\n", launches,
-                h[1], h[2], h[3], h[4], h[5]);
+        fprintf(stderr, "[msm prof, %d launches, 10ns ticks of lane 0 summed over WGs] load %llu D1 %llu D1wait %llu D2 %llu E %llu; D1 shader clock %.0f MHz\n", launches,
+                h[1], h[2], h[3], h[4], h[5], 100.0 * (double)h[6] / (double)h[2]);
     }
 #endif
     return BBP_OK;

@@ -8,15 +8,19 @@
 //   kind 4: sc_montmul chains                                                     -> Montgomery products mod l /s
 //   kind 5: ge_madd chain whose cached point is opaque to the compiler each iteration (as a freshly gathered table row
 //           is: 19 * limb precomputations cannot be hoisted)                       -> mixed additions/s
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "context.h"
 
 namespace bbp {
 
+__device__ unsigned long long g_ubench_clk[2];  // shader-clock and 100 MHz wall-clock ticks of lane 0's loop (BBP_UBENCH_CLK=1 prints MHz)
+
 __global__ __launch_bounds__(256) void k_ubench(int kind, u32 iters, u32* __restrict__ sink) {
     extern __shared__ u32 occupancy_ballast[];  // dynamic LDS only throttles waves/SIMD (BBP_UBENCH_LDS)
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long clk0 = clock64(), wall0 = wall_clock64();
     if (iters == 0xffffffffu) occupancy_ballast[threadIdx.x] = t;
     u32 acc = 0;
     if (kind == 0) {
@@ -79,6 +83,10 @@ __global__ __launch_bounds__(256) void k_ubench(int kind, u32 iters, u32* __rest
         acc = a.v[0] ^ b.v[1];
     }
     sink[t] = acc;
+    if (t == 0) {
+        g_ubench_clk[0] = clock64() - clk0;
+        g_ubench_clk[1] = wall_clock64() - wall0;
+    }
 }
 
 }  // namespace bbp
@@ -106,6 +114,11 @@ extern "C" int32_t bbp_ubench(bbp_ctx* ctx, int32_t kind, uint32_t blocks, uint3
     BBP_HIP_TRY(ctx, hipEventElapsedTime(&ms, a, b));
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
+    if (getenv("BBP_UBENCH_CLK")) {
+        unsigned long long c[2] = {0, 1};
+        (void)hipMemcpyFromSymbol(c, HIP_SYMBOL(g_ubench_clk), sizeof c);
+        fprintf(stderr, "[ubench kind %d] shader clock during the loop: %.0f MHz\n", (int)kind, 100.0 * (double)c[0] / (double)c[1]);
+    }
     const double per_iter[6] = {4, 2, 2, 1, 2, 1};
     *ops_per_sec = per_iter[kind] * (double)blocks * 256.0 * (double)iters / (ms * 1e-3);
     return BBP_OK;
