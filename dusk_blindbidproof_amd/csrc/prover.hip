@@ -910,7 +910,7 @@ int32_t circuit_get(bbp_ctx* ctx, uint32_t n_items, const CircuitDev** out) {
 
 int32_t batch_reserve(bbp_ctx* ctx, uint32_t B, const CircuitDev& c, BatchDev& bd, int parity) {
     const size_t n1 = c.n_mul, m = c.m;
-    DevBuf& buf = parity ? ctx->batch1 : ctx->batch;
+    DevBuf& buf = parity == 2 ? ctx->batch2 : parity ? ctx->batch1 : ctx->batch;  // 0 / 1: the prover's call parities, 2: the verifier
     size_t off = 0;
     auto take = [&](size_t bytes_per_proof) {
         size_t o = off;

@@ -4,13 +4,17 @@
     python tools/stream_bench.py [--bids 65536] [--chunk 1024] [--items 8] [--depth 2]
 
 Bids arrive in host memory in chunks; each chunk is copied H2D (pinned, async), proved, its records verified, and records +
-flags copied back.  `depth` chunks are kept in flight so the copies and the prover's opening stage overlap the previous chunk's
-MSM stage.  Reports sustained proofs/s (= verifies/s) and chunk latency percentiles (host-visible: submit -> results on host).
+flags copied back.  `depth` chunk slots (default 3): inputs are staged one chunk ahead, so the copies and the prover's opening stage overlap the
+previous chunk's MSM stage.  Reports sustained proofs/s (= verifies/s) and chunk latency percentiles (host-visible: submit -> results on host).
 The distinct inputs are a tile of 256 synthetic bids (building 1M witnesses in Python would dominate the run), with fresh
 entropy per chunk so every proof is different.
 """
 import argparse, hashlib, json, os, sys, time
+# the engine itself keeps four streams busy (caller's + opening + two more slices) = HIP's default number of hardware queues;
+# this tool adds a copy stream, and a fifth stream would share a queue with one of them and serialise behind it
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
 import torch
 import dusk_blindbidproof_amd as bbp
 from bench_workloads import synth_bids
@@ -21,7 +25,7 @@ def main():
     ap.add_argument("--bids", type=int, default=65536)
     ap.add_argument("--chunk", type=int, default=1024)
     ap.add_argument("--items", type=int, default=8)
-    ap.add_argument("--depth", type=int, default=2)
+    ap.add_argument("--depth", type=int, default=3)
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     ctx = bbp.Context(0)
@@ -43,8 +47,9 @@ def main():
             d_rec=torch.empty(C * rec, dtype=torch.uint8, device=dev), d_vin=torch.empty(C * v_stride, dtype=torch.uint8, device=dev),
             d_vtail=torch.frombuffer(bytearray(vtail), dtype=torch.uint8).to(dev), d_vent=torch.zeros(C * 32, dtype=torch.uint8, device=dev),
             d_st=torch.full((C,), -1, dtype=torch.int32, device=dev), h_rec=torch.empty(C * rec, dtype=torch.uint8).pin_memory(),
-            h_st=torch.empty(C, dtype=torch.int32).pin_memory(), done=torch.cuda.Event(), t0=None, busy=False))
+            h_st=torch.empty(C, dtype=torch.int32).pin_memory(), done=torch.cuda.Event(), ev_in=torch.cuda.Event(), t0=None, busy=False))
     lat, bad = [], 0
+    ent_np = np.frombuffer(bytearray(b"".join(ents[i % tile] for i in range(C))), dtype=np.uint8).reshape(C, ent_stride).copy()
 
     def finish(sl):
         nonlocal bad
@@ -53,18 +58,21 @@ def main():
         bad += int((sl["h_st"] != 0).sum())
         sl["busy"] = False
 
-    def submit(k, sl):
-        # fresh prover entropy per chunk (host side of the ingest): blindings stay those of the tile, rng seed varies
-        seed = hashlib.shake_256(b"chunk%d" % k).digest(32)
-        base = bytearray(b"".join(ents[i % tile] for i in range(C)))
-        for i in range(C):
-            base[(i + 1) * ent_stride - 32:(i + 1) * ent_stride] = bytes(x ^ (i & 0xff) for x in seed)
-        sl["h_ent"].copy_(torch.frombuffer(base, dtype=torch.uint8))
+    def stage(k, sl):
+        # host side of the ingest, one chunk AHEAD of its prove call: fresh prover entropy per chunk (blindings stay those of the
+        # tile, rng seed varies), then the async H2D copies.  With the GPU saturated a copy can wait tens of milliseconds for its
+        # turn; issued a chunk early that wait is off the critical path (the engine needs complete inputs at call time).
+        seeds = np.frombuffer(hashlib.shake_256(b"chunk%d" % k).digest(32 * C), dtype=np.uint8).reshape(C, 32)
+        ent_np[:, ent_stride - 32:] = seeds
+        sl["h_ent"].copy_(torch.from_numpy(ent_np.reshape(-1)))
         sl["t0"] = time.perf_counter()
         with torch.cuda.stream(cp):
             sl["d_in"].copy_(host_in, non_blocking=True)
             sl["d_ent"].copy_(sl["h_ent"], non_blocking=True)
-        cp.synchronize()  # the engine's opening stage needs complete inputs at call time (include/bbp.h)
+            sl["ev_in"].record(cp)
+
+    def submit(k, sl):
+        sl["ev_in"].synchronize()
         with torch.cuda.stream(sl["st"]):
             s = sl["st"].cuda_stream
             ctx.prove_batch_dev(C, N, sl["d_in"].data_ptr(), sl["d_ent"].data_ptr(), sl["d_rec"].data_ptr(), s)
@@ -78,13 +86,16 @@ def main():
         sl["busy"] = True
 
     # warm-up (allocations, circuit compile)
-    submit(-1, slots[0]); finish(slots[0]); lat.clear()
+    stage(-1, slots[0]); submit(-1, slots[0]); finish(slots[0]); lat.clear()
     t_start = time.perf_counter()
+    stage(0, slots[0])
     for k in range(n_chunks):
-        sl = slots[k % a.depth]
-        if sl["busy"]:
-            finish(sl)
-        submit(k, sl)
+        if k + 1 < n_chunks:
+            nxt = slots[(k + 1) % a.depth]
+            if nxt["busy"]:
+                finish(nxt)
+            stage(k + 1, nxt)
+        submit(k, slots[k % a.depth])
     for sl in slots:
         if sl["busy"]:
             finish(sl)
