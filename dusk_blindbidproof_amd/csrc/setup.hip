@@ -9,6 +9,7 @@
 #include <stdlib.h>
 
 #include "context.h"
+#include "batch.h"
 #include "hosthash.h"
 
 namespace bbp {
@@ -155,6 +156,15 @@ extern "C" void bbp_free(bbp_ctx* ctx) {
                     ctx->slice_vtab[0].p, ctx->slice_vtab[1].p, ctx->slice_vtab[2].p, ctx->slice_vtab[3].p, ctx->comb, ctx->mimc_c, ctx->scal.p, ctx->idx.p, ctx->sorted.p, ctx->pts.p, ctx->enc.p, ctx->misc.p, ctx->batch.p, ctx->io_in.p, ctx->io_out.p, ctx->io_ent.p, ctx->raw.p, ctx->batch1.p, ctx->batch2.p, ctx->slice_sorted[1].p, ctx->slice_sorted[2].p, ctx->slice_sorted[3].p, ctx->slice_pts[1].p, ctx->slice_pts[2].p, ctx->slice_pts[3].p};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    for (auto& kv : ctx->circuits) {  // compiled circuits (one per list length used)
+        bbp::CircuitDev* c = static_cast<bbp::CircuitDev*>(kv.second);
+        if (!c) continue;
+        void* cp[] = {c->w_terms, c->w_loff, c->w_roff, c->f_off, c->f_ent, c->c_q, c->c_cst, c->idx_ai, c->idx_ao, c->idx_ipa, c->idx_ver};
+        for (void* p : cp)
+            if (p) (void)hipFree(p);
+        delete c;
+    }
+    ctx->circuits.clear();
     for (int i = 0; i < 2; i++) {
         if (ctx->ev_in[i]) (void)hipEventDestroy(ctx->ev_in[i]);
         if (ctx->ev_open[i]) (void)hipEventDestroy(ctx->ev_open[i]);
