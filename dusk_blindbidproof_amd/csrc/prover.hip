@@ -3,9 +3,9 @@
 // SURVEY.md App. A.4-A.6) for a whole batch of independent bids.
 //
 // Pipeline (every stage is a device kernel over the batch; the host only sequences launches):
-//   k_witness      one lane per proof interprets the compiled gadget program -> a_L, a_R, a_O            (K3)
+//   k_witness_head / k_open_serial: constants + committed values; one lane per proof interprets the gadget program   (K3)
 //   k_commit       V_i = v_i B + vb_i B~ through the radix-16 comb of the two Pedersen bases                (K2)
-//   k_tr_open      Merlin: "V" x m, "m"; TranscriptRng keyed with the blindings; draws i~,o~,s~,s_L,s_R     (K7)
+//   k_open_serial  Merlin: "V" x m, "m"; TranscriptRng keyed with the blindings; draws i~,o~,s~,s_L,s_R     (K7)
 //   k_msm x3       A_I1, A_O1, S1                                                                            (K1)
 //   k_tr_yz        Merlin: commitments, 1-phase dom-sep, identity A_I2/A_O2/S2, challenges y, z
 //   k_powers       z^k, y^k, y^-k by chunked square-and-multiply
@@ -87,9 +87,8 @@ __device__ sc sc_pow_small(const sc& x, u32 e) {
 // K3: witness
 // ---------------------------------------------------------------------------------------------------------------
 // in_raw per proof: 7 scalars (d,k,y,y_inv,q,z_img,seed) || N items || toggle(u64)
-__global__ void k_witness(u32 B, u32 n_items, u32 n_mul, u32 n_cst, const u8* __restrict__ in_raw, const u32* __restrict__ w_terms,
-                          const u32* __restrict__ w_loff, const u32* __restrict__ w_roff, sc* __restrict__ cst_all,
-                          sc* __restrict__ v_all, sc* __restrict__ ai1_all, sc* __restrict__ ao1_all, int prover) {
+// head: constants and committed values of every proof (cheap, what the V commitments need)
+__global__ void k_witness_head(u32 B, u32 n_items, u32 n_cst, const u8* __restrict__ in_raw, sc* __restrict__ cst_all, sc* __restrict__ v_all) {
     u32 p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= B) return;
     const size_t in_stride = 7 * 32 + (size_t)n_items * 32 + 8;
@@ -104,7 +103,6 @@ __global__ void k_witness(u32 B, u32 n_items, u32 n_mul, u32 n_cst, const u8* __
     st_sc(&cst[circuit::CST_ZIMG], s7[5]);
     st_sc(&cst[circuit::CST_Q], s7[4]);
     for (u32 i = 0; i < n_items; i++) st_sc(&cst[circuit::CST_ITEM0 + i], sc_from_bits(in + 56 + 8 * i));  // bid.rs:27
-    if (!prover) return;
     sc* v = v_all + (size_t)p * m;
     const u32 toggle = in[56 + 8 * n_items];
     st_sc(&v[0], s7[0]);
@@ -112,6 +110,14 @@ __global__ void k_witness(u32 B, u32 n_items, u32 n_mul, u32 n_cst, const u8* __
     st_sc(&v[2], s7[2]);  // y: committed but never wired into the gadget (proof.rs:55, 76-78)
     st_sc(&v[3], s7[3]);
     for (u32 i = 0; i < n_items; i++) st_sc(&v[4 + i], i == toggle ? sc_one() : sc_zero());
+}
+
+// gates: one lane interprets the compiled gadget program of its proof (sequential MiMC chains) -> a_L, a_R, a_O
+__device__ void witness_gates_lane(u32 p, u32 m, u32 n_mul, u32 n_cst, const u32* __restrict__ w_terms, const u32* __restrict__ w_loff,
+                                   const u32* __restrict__ w_roff, const sc* __restrict__ cst_all, const sc* __restrict__ v_all,
+                                   sc* __restrict__ ai1_all, sc* __restrict__ ao1_all) {
+    const sc* cst = cst_all + (size_t)p * n_cst;
+    const sc* v = v_all + (size_t)p * m;
     sc* aL = ai1_all + (size_t)p * (1 + 2 * n_mul) + 1;
     sc* aR = aL + n_mul;
     sc* aO = ao1_all + (size_t)p * (1 + n_mul) + 1;
@@ -213,11 +219,9 @@ __global__ void k_encode_strided(u32 count, u32 per_proof, const ge* __restrict_
 // enc layout per proof (words): V[m] | A_I1 A_O1 S1 | T_1 T_3 T_4 T_5 T_6 | (L_j R_j) x 11
 __device__ __forceinline__ u32 enc_stride_words(u32 m) { return (m + 8 + 22) * 8; }
 
-__global__ void k_tr_open(u32 B, u32 m, u32 n1, merlin_transcript prefix, const u32* __restrict__ enc, const u8* __restrict__ entropy,
-                          sc* __restrict__ vb_all, u32* __restrict__ raw, merlin_transcript* __restrict__ tr_out,
-                          merlin_transcript* __restrict__ rng_out) {
-    u32 p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= B) return;
+__device__ void tr_open_lane(u32 p, u32 m, u32 n1, const merlin_transcript& prefix, const u32* __restrict__ enc, const u8* __restrict__ entropy,
+                             const sc* __restrict__ vb_all, u32* __restrict__ raw, merlin_transcript* __restrict__ tr_out,
+                             merlin_transcript* __restrict__ rng_out) {
     merlin_transcript t = prefix;  // Transcript::new(b"BlindBidProofGadget") + r1cs_domain_sep (A.4)
     const u32* e = enc + (size_t)p * enc_stride_words(m);
     for (u32 i = 0; i < m; i++) tr_append_words(t, LBL("V"), e + 8 * i);
@@ -245,6 +249,23 @@ __global__ void k_tr_open(u32 B, u32 m, u32 n1, merlin_transcript prefix, const 
     merlin_rng_fill64_bulk(r, 2 + 2 * n1, rw + 16);
     tr_out[p] = t;
     rng_out[p] = r;
+}
+
+// The two strictly serial jobs of the opening stage in ONE launch: the first `rng_blocks` workgroups run the transcript opening +
+// the 2935 sequential rng draws of their proofs, the others interpret the gadget program of theirs.  Neither needs the other
+// (the V commitments only need k_witness_head), so the opening stage lasts max(36 ms, 6 ms) instead of their sum.
+__global__ void k_open_serial(u32 B, u32 rng_blocks, u32 m, u32 n1, merlin_transcript prefix, const u32* __restrict__ enc,
+                              const u8* __restrict__ entropy, const sc* __restrict__ vb_all, u32* __restrict__ raw,
+                              merlin_transcript* __restrict__ tr_out, merlin_transcript* __restrict__ rng_out, u32 n_cst,
+                              const u32* __restrict__ w_terms, const u32* __restrict__ w_loff, const u32* __restrict__ w_roff,
+                              const sc* __restrict__ cst_all, const sc* __restrict__ v_all, sc* __restrict__ ai1_all, sc* __restrict__ ao1_all) {
+    if (blockIdx.x < rng_blocks) {
+        const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+        if (p < B) tr_open_lane(p, m, n1, prefix, enc, entropy, vb_all, raw, tr_out, rng_out);
+    } else {
+        const u32 p = (blockIdx.x - rng_blocks) * blockDim.x + threadIdx.x;
+        if (p < B) witness_gates_lane(p, m, n1, n_cst, w_terms, w_loff, w_roff, cst_all, v_all, ai1_all, ao1_all);
+    }
 }
 
 // draw j of proof p -> its scalar slot: 0 -> ai1[0], 1 -> ao1[0], 2 -> s1[0], j >= 3 -> s1[1 + (j - 3)]
@@ -961,7 +982,7 @@ static merlin_transcript prover_prefix() {
 // every other launch carries a token 64 bytes of LDS so that it, too, stays off the fully reserved CUs
 #define LAUNCH(ctx, tag, kern, grid, block, stream, ...) LAUNCH_LDS(ctx, tag, kern, grid, block, lds_token(ctx), stream, __VA_ARGS__)
 
-// The one-lane-per-proof kernels of the opening stage (k_witness, k_tr_open: 16 wavefronts that run for tens of
+// The one-lane-per-proof kernels of the opening stage (k_open_serial: 32 wavefronts that run for tens of
 // milliseconds) overlap the previous batch's heavy stage.  Sharing a SIMD with them is poison for that stage: the long-lived
 // wave is the oldest on its SIMD and wins issue arbitration, the MSM workgroup next to it runs several times slower, and
 // since a 1024-workgroup launch is placed in one round, every kernel then lasts as long as its slowest workgroup (measured:
@@ -1016,16 +1037,15 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
         // made (include/bbp.h).  Waiting on the caller's stream tail would serialise it behind the previous call's heavy stage.
         if (ctx->ev_done_valid[par]) BBP_HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_done[par], 0));
         LAUNCH(ctx, TAG_WITNESS, k_fill_mimc, cdiv(B * BBP_MIMC_ROUNDS, 64), 64, s, B, c.n_cst, ctx->mimc_c, bd.cst);
-        if ((rc = serial_lds_bytes(ctx, (const void*)k_witness)) || (rc = serial_lds_bytes(ctx, (const void*)k_tr_open))) return rc;
+        if ((rc = serial_lds_bytes(ctx, (const void*)k_open_serial))) return rc;
         const u32 hog = ctx->serial_lds > 0 ? (u32)ctx->serial_lds : 0u;
-        // 4 waves per workgroup: one serial wave per SIMD, a quarter as many CUs taken out of the heavy stage's pool
         const u32 sblk = hog ? (u32)ctx->serial_block : 64u;
-        LAUNCH_LDS(ctx, TAG_WITNESS, k_witness, cdiv(B, sblk), sblk, hog, s, B, N, n1, c.n_cst, in_dev, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v,
-                   bd.ai1, bd.ao1, 1);
+        LAUNCH(ctx, TAG_WITNESS, k_witness_head, cdiv(B, 64), 64, s, B, N, c.n_cst, in_dev, bd.cst, bd.v);
         LAUNCH(ctx, TAG_TRANSCRIPT, k_load_blindings, cdiv(B * m, 64), 64, s, B, m, ent_dev, bd.vb);
         if ((rc = commit_launch(ctx, B * m, bd.v, bd.vb, m, m, m, bd.pts, m + 8, s))) return rc;
         LAUNCH(ctx, TAG_ENCODE, k_encode_strided, cdiv(B * m, 64), 64, s, B * m, m, bd.pts, m + 8, bd.enc, encw, 0u);
-        LAUNCH_LDS(ctx, TAG_RNG, k_tr_open, cdiv(B, sblk), sblk, hog, s, B, m, n1, prefix, bd.enc, ent_dev, bd.vb, (u32*)ctx->raw.p, bd.tr, bd.rng);
+        LAUNCH_LDS(ctx, TAG_RNG, k_open_serial, 2 * cdiv(B, sblk), sblk, hog, s, B, cdiv(B, sblk), m, n1, prefix, bd.enc, ent_dev, bd.vb,
+                   (u32*)ctx->raw.p, bd.tr, bd.rng, c.n_cst, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v, bd.ai1, bd.ao1);
         LAUNCH(ctx, TAG_RNG, k_reduce_draws, cdiv((u32)(B * n_draws), 128), 128, s, B, n1, (const u32*)ctx->raw.p, bd.ai1, bd.ao1, bd.s1);
         BBP_HIP_TRY(ctx, hipEventRecord(ctx->ev_open[par], s));
         ctx->ev_open_valid[par] = true;
