@@ -140,27 +140,30 @@ template <> struct msm_geom<0> { static constexpr int K = MSM_K, NAF = MSM_NAF, 
 template <> struct msm_geom<1> { static constexpr int K = FOLD_K, NAF = FOLD_NAF, W = FOLD_W; };
 
 template <int MODE>
-__global__ __launch_bounds__(SORT_T) void k_msm_sort(const u32* __restrict__ scal_a, const u32* __restrict__ aux, u32 n, u32 n_idx_sets,
-                                                      u32* __restrict__ sorted_all, u32* __restrict__ cursor_all) {
+__global__ __launch_bounds__(SORT_T) void k_msm_sort(const u32* __restrict__ scal_a, const u32* __restrict__ aux, u32 n_total, u32 n_idx_sets,
+                                                      u32 n_sub, u32 split, u32* __restrict__ sorted_all, u32* __restrict__ cursor_all) {
     constexpr int K = msm_geom<MODE>::K, NAF = msm_geom<MODE>::NAF, W = msm_geom<MODE>::W, G = K / SORT_T;
     __shared__ u32 cursor[K + 1];  // histogram, then bucket start offsets, then (after the scatter) bucket end offsets
     __shared__ u32 part[SORT_T];
     const int tid = threadIdx.x;
-    const size_t msm = blockIdx.x;
+    // small batches: every MSM is cut into `split` sub-MSMs over n_sub consecutive terms (one workgroup each, summed afterwards)
+    const size_t work = blockIdx.x, msm = work / split;
+    const u32 i0 = (u32)(work % split) * n_sub;
+    const u32 n = i0 < n_total ? min(n_sub, n_total - i0) : 0u;
     __builtin_amdgcn_s_setprio(3);  // thin kernel: see BBP_THIN_PRIO in prover.hip
     const u32* sbase;
     const u32* base_idx = nullptr;
     u32 base0 = 0;
     if (MODE == 0) {
-        sbase = scal_a + msm * (size_t)n * 8;
-        base_idx = aux + (size_t)(blockIdx.x % n_idx_sets) * n;
+        sbase = scal_a + (msm * (size_t)n_total + i0) * 8;
+        base_idx = aux + (size_t)(msm % n_idx_sets) * n_total + i0;
     } else {
-        const u32 side = blockIdx.x & 1u;  // 0: G with g[], 1: H with h[]
-        sbase = (side ? aux : scal_a) + (msm >> 1) * (size_t)2048 * 8;
-        base0 = side ? BBP_BASE_H0 : BBP_BASE_G0;
+        const u32 side = (u32)msm & 1u;  // 0: G with g[], 1: H with h[]
+        sbase = (side ? aux : scal_a) + ((msm >> 1) * (size_t)2048 + i0) * 8;
+        base0 = (side ? BBP_BASE_H0 : BBP_BASE_G0) + i0;
     }
-    u32* sorted = sorted_all + msm * (size_t)n * W;
-    auto key = [&](u32 i, u32 mag) -> u32 { return (MODE == 0 ? 0u : (i & (FOLD_CLS - 1)) * FOLD_M) + ((mag + 1) >> 1); };
+    u32* sorted = sorted_all + work * (size_t)n_sub * W;
+    auto key = [&](u32 i, u32 mag) -> u32 { return (MODE == 0 ? 0u : ((i0 + i) & (FOLD_CLS - 1)) * FOLD_M) + ((mag + 1) >> 1); };
 
     for (int k = tid; k <= K; k += SORT_T) cursor[k] = 0;
     __syncthreads();
@@ -207,13 +210,13 @@ __global__ __launch_bounds__(SORT_T) void k_msm_sort(const u32* __restrict__ sca
         });
     }
     __syncthreads();
-    u32* cur_out = cursor_all + msm * (size_t)(K + 1);
+    u32* cur_out = cursor_all + work * (size_t)(K + 1);
     for (int k = tid; k <= K; k += SORT_T) cur_out[k] = k ? cursor[k] : 0u;  // cursor[k] = end offset of bucket k
 }
 
 template <int MODE>
 __global__ __launch_bounds__(MSM_T) __attribute__((amdgpu_waves_per_eu(BBP_MSM_WAVES, BBP_MSM_WAVES_MAX)))
-void k_msm_acc(const niels_row* __restrict__ ptable, const u32* __restrict__ sorted_all, const u32* __restrict__ cursor_all, u32 n,
+void k_msm_acc(const niels_row* __restrict__ ptable, const u32* __restrict__ sorted_all, const u32* __restrict__ cursor_all, u32 n /* sorted stride */,
                ge* __restrict__ bsum_all, ge* __restrict__ psum_all, ge* __restrict__ out) {
     constexpr int K = msm_geom<MODE>::K, W = msm_geom<MODE>::W, G = K / MSM_T;
     __shared__ u32 cursor[K + 1];
@@ -236,7 +239,7 @@ void k_msm_acc(const niels_row* __restrict__ ptable, const u32* __restrict__ sor
     //     bucket sizes are (a scalar repeated hundreds of times -- the padding rows of the first IPA round -- would
     //     otherwise serialise one lane).  A chunk that starts inside a bucket parks that leading partial sum in psum[lane];
     //     every other bucket (or bucket head) it meets goes to bsum[bucket].
-    const u32 E = cursor[K];
+    const u32 E = cursor[K];  // may be 0 (an empty sub-MSM): then no chunk has entries and no bucket is non-empty, E never divides
     ge* bsum = bsum_all + msm * (size_t)K;               // [K] bucket k at index k-1
     ge* psum = psum_all + msm * (size_t)MSM_T;           // [T]
     const u32 c0 = (u32)(((u64)tid * E) / MSM_T), c1 = (u32)(((u64)(tid + 1) * E) / MSM_T);
@@ -366,14 +369,36 @@ void k_msm_acc(const niels_row* __restrict__ ptable, const u32* __restrict__ sor
     MSM_PROF_MARK(5);
 }
 
+// sums the `split` partial results of every MSM: out[o] = sum_j tmp[((o / items) * split + j) * items + o % items]
+__global__ void k_msm_reduce(u32 n_out, u32 split, u32 items, const ge* __restrict__ tmp, ge* __restrict__ out) {
+    __builtin_amdgcn_s_setprio(3);
+    u32 o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n_out) return;
+    const u32 msm = o / items, c = o % items;
+    ge acc = tmp[((size_t)msm * split) * items + c];
+    for (u32 j = 1; j < split; j++) acc = ge_add(acc, tmp[((size_t)msm * split + j) * items + c]);
+    out[o] = acc;
+}
+
+// how many workgroups an MSM of n terms is cut into when the launch has only n_msm of them (fills the GPU for small batches)
+static u32 msm_split(u32 n_msm, u32 n_terms) {
+    // every sub-MSM pays the full bucket fold (phases D2, E), so splitting only pays while the GPU would otherwise be mostly
+    // empty: measured, B = 256 in three slices (170 MSMs per launch) is better off unsplit
+    if (n_msm >= 128) return 1;
+    u32 s = 512 / n_msm;
+    if (s > 16) s = 16;
+    while (s > 1 && n_terms / s < 128) s--;
+    return s ? s : 1;
+}
+
 // scratch of one launch: sorted entries (n * W u32 per MSM) | bucket end offsets (K + 1 u32) | bucket sums (K points) |
 // chunk-leading partial sums (T points)
 struct MsmScratch {
     u32 *sorted, *cursor;
-    ge *bsum, *psum;
+    ge *bsum, *psum, *tmp;  // tmp: partial results of split MSMs
     size_t bytes;
 };
-static MsmScratch msm_scratch_layout(void* base, size_t n_msm, size_t n_terms, size_t W, size_t K) {
+static MsmScratch msm_scratch_layout(void* base, size_t n_msm, size_t n_terms, size_t W, size_t K, size_t out_items = 1) {
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
     MsmScratch m;
     size_t o = 0;
@@ -385,27 +410,41 @@ static MsmScratch msm_scratch_layout(void* base, size_t n_msm, size_t n_terms, s
     o += n_msm * K * sizeof(ge);
     m.psum = reinterpret_cast<ge*>(static_cast<u8*>(base) + o);
     o += n_msm * MSM_T * sizeof(ge);
+    m.tmp = reinterpret_cast<ge*>(static_cast<u8*>(base) + o);
+    o += n_msm * out_items * sizeof(ge);
     m.bytes = o;
     return m;
 }
-size_t msm_scratch_bytes(uint32_t n_msm, uint32_t n_terms) { return msm_scratch_layout(nullptr, n_msm, n_terms, MSM_W, MSM_K).bytes; }
+size_t msm_scratch_bytes(uint32_t n_msm, uint32_t n_terms) {
+    const u32 split = msm_split(n_msm, n_terms), n_sub = (n_terms + split - 1) / split;
+    return msm_scratch_layout(nullptr, (size_t)n_msm * split, n_sub, MSM_W, MSM_K).bytes;
+}
 
 int32_t fold_generators_launch(bbp_ctx* ctx, uint32_t n_proofs, const sc* g_dev, const sc* h_dev, ge* out_dev, hipStream_t stream,
                                int scratch_slot) {
     if (n_proofs == 0) return BBP_OK;
     const size_t n_msm = 2 * (size_t)n_proofs;
+    const u32 split = msm_split((u32)n_msm, 2048), n_sub = (2048 + split - 1) / split;
+    const size_t n_work = n_msm * split;
     DevBuf& scratch = ctx->slice_fold[scratch_slot];
-    int32_t rc = dev_reserve(ctx, scratch, msm_scratch_layout(nullptr, n_msm, 2048, FOLD_W, FOLD_K).bytes);
+    int32_t rc = dev_reserve(ctx, scratch, msm_scratch_layout(nullptr, n_work, n_sub, FOLD_W, FOLD_K, FOLD_CLS).bytes);
     if (rc) return rc;
-    const MsmScratch m = msm_scratch_layout(scratch.p, n_msm, 2048, FOLD_W, FOLD_K);
+    const MsmScratch m = msm_scratch_layout(scratch.p, n_work, n_sub, FOLD_W, FOLD_K, FOLD_CLS);
     {
         ScopedEvent ev(ctx, TAG_MSM_SORT, stream);
-        hipLaunchKernelGGL(k_msm_sort<1>, dim3((u32)n_msm), dim3(SORT_T), 0, stream, (const u32*)g_dev, (const u32*)h_dev, 2048u, 1u, m.sorted, m.cursor);
+        hipLaunchKernelGGL(k_msm_sort<1>, dim3((u32)n_work), dim3(SORT_T), 0, stream, (const u32*)g_dev, (const u32*)h_dev, 2048u, 1u, n_sub, split,
+                           m.sorted, m.cursor);
         BBP_HIP_TRY(ctx, hipGetLastError());
     }
     ScopedEvent ev(ctx, TAG_MSM, stream);
-    hipLaunchKernelGGL(k_msm_acc<1>, dim3((u32)n_msm), dim3(MSM_T), 0, stream, ctx->ptable, m.sorted, m.cursor, 2048u, m.bsum, m.psum, out_dev);
+    hipLaunchKernelGGL(k_msm_acc<1>, dim3((u32)n_work), dim3(MSM_T), 0, stream, ctx->ptable, m.sorted, m.cursor, n_sub, m.bsum, m.psum,
+                       split > 1 ? m.tmp : out_dev);
     BBP_HIP_TRY(ctx, hipGetLastError());
+    if (split > 1) {
+        const u32 n_out = (u32)n_msm * FOLD_CLS;
+        hipLaunchKernelGGL(k_msm_reduce, dim3((n_out + 63) / 64), dim3(64), lds_token(ctx), stream, n_out, split, (u32)FOLD_CLS, m.tmp, out_dev);
+        BBP_HIP_TRY(ctx, hipGetLastError());
+    }
     return BBP_OK;
 }
 
@@ -430,15 +469,23 @@ int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* sc
     DevBuf& scratch = scratch_slot ? ctx->slice_sorted[scratch_slot] : ctx->sorted;  // one scratch area per concurrently running stream
     int32_t rc = dev_reserve(ctx, scratch, msm_scratch_bytes(n_msm, n_terms));
     if (rc) return rc;
-    const MsmScratch m = msm_scratch_layout(scratch.p, n_msm, n_terms, MSM_W, MSM_K);
+    const u32 split = msm_split(n_msm, n_terms), n_sub = (n_terms + split - 1) / split;
+    const u32 n_work = n_msm * split;
+    const MsmScratch m = msm_scratch_layout(scratch.p, n_work, n_sub, MSM_W, MSM_K);
     {
         ScopedEvent ev(ctx, TAG_MSM_SORT, stream);
-        hipLaunchKernelGGL(k_msm_sort<0>, dim3(n_msm), dim3(SORT_T), 0, stream, scalars_dev, base_idx_dev, n_terms, n_idx_sets, m.sorted, m.cursor);
+        hipLaunchKernelGGL(k_msm_sort<0>, dim3(n_work), dim3(SORT_T), 0, stream, scalars_dev, base_idx_dev, n_terms, n_idx_sets, n_sub, split,
+                           m.sorted, m.cursor);
         BBP_HIP_TRY(ctx, hipGetLastError());
     }
     ScopedEvent ev(ctx, TAG_MSM, stream);
-    hipLaunchKernelGGL(k_msm_acc<0>, dim3(n_msm), dim3(MSM_T), 0, stream, ctx->ptable, m.sorted, m.cursor, n_terms, m.bsum, m.psum, out_points_dev);
+    hipLaunchKernelGGL(k_msm_acc<0>, dim3(n_work), dim3(MSM_T), 0, stream, ctx->ptable, m.sorted, m.cursor, n_sub, m.bsum, m.psum,
+                       split > 1 ? m.tmp : out_points_dev);
     BBP_HIP_TRY(ctx, hipGetLastError());
+    if (split > 1) {
+        hipLaunchKernelGGL(k_msm_reduce, dim3((n_msm + 63) / 64), dim3(64), lds_token(ctx), stream, n_msm, split, 1u, m.tmp, out_points_dev);
+        BBP_HIP_TRY(ctx, hipGetLastError());
+    }
 #ifdef BBP_MSM_PROF
     static int launches = 0;
     if (++launches % 16 == 0) {
