@@ -4,7 +4,7 @@ import os
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-TAG_NAMES = {1: "k_msm_acc", 11: "k_msm_sort", 2: "k_encode", 3: "k_witness", 4: "k_tr_open(rng)", 5: "k_poly/powers/flatten", 6: "k_ipa_round", 7: "k_commit",
+TAG_NAMES = {1: "k_msm_acc", 11: "k_msm_sort", 2: "k_encode", 3: "k_witness_head", 4: "k_open_serial(witness+rng)", 5: "k_poly/powers/flatten", 6: "k_ipa_round", 7: "k_commit",
              8: "k_transcript", 9: "k_vscalars", 10: "k_varbase/tail"}
 L = 2**252 + 27742317777372353535851937790883648493
 
@@ -171,7 +171,7 @@ class ProveWorkload(_Base):
         ref_terms = 2 * (4 + items) + 5 * n1 + 3 + 11 + 8210 + 8188
         self.alg_bytes_per_step = batch * (ref_terms * 160 + 32 * ((4 + items) + 8 + 22))
         # what the engine's MSM kernels actually add (fold-free IPA: rounds 1-6 are 2 x 2049-term MSMs over the original generators,
-        # then one composite-bucket pass over all 4096 generators; the tail rounds are variable-base work outside k_msm)
+        # then one composite-bucket pass over all 4096 generators; the tail rounds are variable-base work outside the MSM kernels)
         engine_terms = commit_terms + 6 * 2 * 2049
         self.row_additions_per_step = batch * (engine_terms * NAF12_DIGITS + 4096 * NAF9_DIGITS)
         self.dominant_launches_per_step = 3 + 6 + 1

@@ -22,7 +22,7 @@ constexpr int MSM_T = 128;                // threads per MSM workgroup (2 wavefr
 constexpr int MSM_G = MSM_K / MSM_T;      // 8 consecutive buckets per lane
 constexpr int MSM_LOG_G = 3;
 // IPA tail (prover.hip): from round FOLD_ROUND the folded generators are explicit points; they are materialised by a
-// composite-bucket Pippenger pass over the same row table (msm.hip k_fold_generators)
+// composite-bucket Pippenger pass over the same row table (msm.hip, the <1> instances of k_msm_sort / k_msm_acc)
 constexpr int FOLD_ROUND = 7;              // first tail round: vectors of length 32 (halves of 16)
 constexpr int FOLD_CLS = 2048 >> (FOLD_ROUND - 1);  // 32 folded generators per side
 constexpr int FOLD_NAF = 9;                // width-9 NAF: odd digits |d| < 256

@@ -6,17 +6,18 @@
 //   k_witness_head / k_open_serial: constants + committed values; one lane per proof interprets the gadget program   (K3)
 //   k_commit       V_i = v_i B + vb_i B~ through the radix-16 comb of the two Pedersen bases                (K2)
 //   k_open_serial  Merlin: "V" x m, "m"; TranscriptRng keyed with the blindings; draws i~,o~,s~,s_L,s_R     (K7)
-//   k_msm x3       A_I1, A_O1, S1                                                                            (K1)
+//   MSM x3         A_I1, A_O1, S1 (msm.hip: k_msm_sort + k_msm_acc)                                            (K1)
 //   k_tr_yz        Merlin: commitments, 1-phase dom-sep, identity A_I2/A_O2/S2, challenges y, z
 //   k_powers       z^k, y^k, y^-k by chunked square-and-multiply
 //   k_flatten      wL, wR, wO, wV = sparse gather of z powers (circuit structure is shared by the batch)   (K4)
 //   k_poly         l1, r0, r1, r3 and the six t coefficients, block reduction in LDS                        (K5)
 //   k_tr_tblind / k_commit / k_tr_ux   T_1,3,4,5,6, challenges u, x, t_x, t_x~, e~, challenge w
 //   k_lrvec        l(x), r(x) and the per-generator factor vectors g[k], h[k]
-//   11 x { k_ipa_round, k_msm (2 per proof), k_encode }                                                      (K6)
+//   rounds 1-6:  { k_ipa_challenge, k_ipa_round, MSM (2 per proof), k_encode }                               (K6)
+//   round 7:     generator fold (MSM kernels <1>), k_tail_tables; rounds 7-11: { k_tail_lr, k_encode }
 //   k_ipa_final, k_assemble
 //
-// The inner-product argument never folds the generator vectors.  Round j's L and R are multiscalar multiplications
+// The inner-product argument never folds the generator vectors point by point.  Round j's L and R (j <= 6) are multiscalar multiplications
 // over the ORIGINAL resident generators with scalars a[i] * g[k] / b[i] * h[k], where g[k], h[k] accumulate the
 // challenge products u_r^(+-1) that the reference applies by folding G and H (A.6).  The group elements are equal,
 // encodings are canonical, hence identical bytes -- and every MSM of the prover is a fixed-base MSM over one table.
@@ -720,7 +721,7 @@ __device__ ge ge_scalarmul_pieces(const sc& s, const ge* __restrict__ T) {
 }
 
 // The tail never folds points either: like the main rounds it keeps per-generator factor scalars (gg, hh: 32 each, stored in
-// the first 32 slots of bd.g / bd.h once the big factor vectors have been consumed by k_fold_generators) and multiplies
+// the first 32 slots of bd.g / bd.h once the big factor vectors have been consumed by the generator-fold MSM) and multiplies
 // them into the term scalars.  Every tail round is then ONE launch of 2 x 33 independent scalar multiplications per proof.
 __global__ void k_tail_init(u32 B, sc* __restrict__ g_all, sc* __restrict__ h_all) {
     BBP_THIN_PRIO();
@@ -986,7 +987,7 @@ static merlin_transcript prover_prefix() {
 // milliseconds) overlap the previous batch's heavy stage.  Sharing a SIMD with them is poison for that stage: the long-lived
 // wave is the oldest on its SIMD and wins issue arbitration, the MSM workgroup next to it runs several times slower, and
 // since a 1024-workgroup launch is placed in one round, every kernel then lasts as long as its slowest workgroup (measured:
-// k_msm 3.3 ms -> 19.5 ms while k_tr_open is resident; 107 ms -> 78 ms per batch without it).  So these launches ask for
+// the MSM kernel 3.3 ms -> 19.5 ms while the rng kernel is resident; 107 ms -> 78 ms per batch without it).  So these launches ask for
 // nearly a whole CU's LDS, which they never touch: no LDS-using workgroup (every heavy kernel that matters) can be placed
 // beside them, the dispatcher routes those to the other ~240 CUs, and the serial wave has its CU to itself.
 static int32_t serial_lds_bytes(bbp_ctx* ctx, const void* kernel) {
