@@ -18,9 +18,13 @@ constexpr int MSM_NAF = 12;               // scalar recoding: width-12 NAF, odd 
 constexpr int MSM_POS = 256;              // table rows per generator: 2^b * P for every bit position b
 constexpr int MSM_W = 22;                 // most digits one scalar can have (positions >= 12 apart, last <= 253)
 constexpr int MSM_K = 1 << (MSM_NAF - 2); // 1024 buckets: bucket k holds the digit magnitude 2k - 1
-constexpr int MSM_T = 128;                // threads per MSM workgroup (2 wavefronts)
-constexpr int MSM_G = MSM_K / MSM_T;      // 8 consecutive buckets per lane
-constexpr int MSM_LOG_G = 3;
+#ifndef BBP_MSM_T
+#define BBP_MSM_T 128
+#endif
+constexpr int MSM_T = BBP_MSM_T;          // lanes of the accumulate workgroup: 128 (2 wavefronts; -DBBP_MSM_T=64 for experiments)
+constexpr int MSM_G = MSM_K / MSM_T;      // consecutive buckets per lane (8)
+constexpr int MSM_LOG_G = MSM_T == 128 ? 3 : 4;
+static_assert(MSM_T == 128 || MSM_T == 64, "the cross-lane fold is written for one or two wavefronts");
 // IPA tail (prover.hip): from round FOLD_ROUND the folded generators are explicit points; they are materialised by a
 // composite-bucket Pippenger pass over the same row table (msm.hip, the <1> instances of k_msm_sort / k_msm_acc)
 constexpr int FOLD_ROUND = 7;              // first tail round: vectors of length 32 (halves of 16)

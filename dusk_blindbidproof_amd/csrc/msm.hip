@@ -305,18 +305,20 @@ void k_msm_acc(const niels_row* __restrict__ ptable, const u32* __restrict__ sor
     }
     MSM_PROF_MARK(4);
 
-    if (MODE == 0) {
+    if constexpr (MODE == 0) {
         // E. cross-lane fold: W = sum_k k S_k = sum_t total_t + G * sum_{t>=1} suffix_t, suffix_t = sum_{u>=t} running_u
         const int lane = tid & 63, wave = tid >> 6;
         for (int d = 1; d < 64; d <<= 1) {  // suffix scan inside each wavefront
             ge other = ge_shfl_down(running, d);
             if (lane + d < 64) ge_add_nc(running, running, other);
         }
-        if (tid == 64) xch_put(xch, running);  // = sum over the upper wavefront
-        __syncthreads();
-        if (wave == 0) {
-            ge other = xch_get(xch);
-            ge_add_nc(running, running, other);
+        if (MSM_T > 64) {
+            if (tid == 64) xch_put(xch, running);  // = sum over the upper wavefront
+            __syncthreads();
+            if (wave == 0) {
+                ge other = xch_get(xch);
+                ge_add_nc(running, running, other);
+            }
         }
         ge x = total;
         if (tid >= 1) {
@@ -328,12 +330,17 @@ void k_msm_acc(const niels_row* __restrict__ ptable, const u32* __restrict__ sor
             ge other = ge_shfl_down(x, d);
             if (lane < d) ge_add_nc(x, x, other);
         }
-        __syncthreads();
-        if (tid == 64) xch_put(xch, x);
-        __syncthreads();
+        if (MSM_T > 64) {
+            __syncthreads();
+            if (tid == 64) xch_put(xch, x);
+            __syncthreads();
+        }
         if (tid == 0) {
-            ge other = xch_get(xch);
-            ge_add_nc(x, x, other);
+            if (MSM_T > 64) {
+                ge other = xch_get(xch);
+                ge_add_nc(x, x, other);
+            }
+            ge other;
             // bucket k holds the digit 2k - 1: result = 2 W - S, S = suffix_0 = lane 0's running
             ge_dbl_nc(x, x);
             other = ge_neg(running);
@@ -341,29 +348,31 @@ void k_msm_acc(const niels_row* __restrict__ ptable, const u32* __restrict__ sor
             out[msm] = x;
         }
     } else {
-        // class (4 lanes x 32 keys): W = sum_q total_q + 32 * sum_{q>=1} suffix_q, S = suffix_0; result = 2 W - S
-        const int q = tid & 3;
+        // class (LPC lanes x G keys): W = sum_q total_q + G * sum_{q>=1} suffix_q, S = suffix_0; result = 2 W - S
+        constexpr int LPC = FOLD_M / G, LOG_G2 = G == 32 ? 5 : 6;
+        static_assert(G == 32 || G == 64, "class reduction written for 4 or 2 lanes per class");
+        const int q = tid & (LPC - 1);
         ge suf = running;
-        for (int d = 1; d < 4; d++) {
+        for (int d = 1; d < LPC; d++) {
             ge other = ge_shfl_down(running, d);
-            if (q + d < 4) ge_add_nc(suf, suf, other);
+            if (q + d < LPC) ge_add_nc(suf, suf, other);
         }
         ge x = total;
         if (q >= 1) {
-            ge s32 = suf;
-            for (int i = 0; i < 5; i++) ge_dbl_nc(s32, s32);
-            ge_add_nc(x, x, s32);
+            ge sg = suf;
+            for (int i = 0; i < LOG_G2; i++) ge_dbl_nc(sg, sg);
+            ge_add_nc(x, x, sg);
         }
-        ge acc4 = x;
-        for (int d = 1; d < 4; d++) {
+        ge accq = x;
+        for (int d = 1; d < LPC; d++) {
             ge other = ge_shfl_down(x, d);
-            if (q == 0) ge_add_nc(acc4, acc4, other);
+            if (q == 0) ge_add_nc(accq, accq, other);
         }
         if (q == 0) {
-            ge_dbl_nc(acc4, acc4);
+            ge_dbl_nc(accq, accq);
             ge other = ge_neg(suf);
-            ge_add_nc(acc4, acc4, other);
-            out[msm * FOLD_CLS + (tid >> 2)] = acc4;
+            ge_add_nc(accq, accq, other);
+            out[msm * FOLD_CLS + (tid / LPC)] = accq;
         }
     }
     MSM_PROF_MARK(5);
