@@ -520,8 +520,10 @@ __global__ void k_lrvec(u32 B, u32 n1, const sc* __restrict__ l1, const sc* __re
     }
     st_sc(&a[(size_t)p * 2048 + i], av);
     st_sc(&b[(size_t)p * 2048 + i], bv);
-    st_sc(&g[(size_t)p * 2048 + i], gv);
-    st_sc(&h[(size_t)p * 2048 + i], sc_mul(ld_sc(&yipow[(size_t)p * 2048 + i]), gv));
+    // the factor vectors live in Montgomery form (x R mod l) through the MSM rounds: every use is a product with a plain
+    // scalar, which then costs ONE Montgomery multiplication instead of two (k_ipa_round)
+    st_sc(&g[(size_t)p * 2048 + i], sc_to_mont(gv));
+    st_sc(&h[(size_t)p * 2048 + i], sc_montmul(sc_to_mont(ld_sc(&yipow[(size_t)p * 2048 + i])), sc_to_mont(gv)));
 }
 
 // Fiat-Shamir step between IPA rounds: absorb L_j, R_j (j = prev_round), draw u_j, invert it.  One lane per proof.
@@ -562,19 +564,23 @@ __global__ __launch_bounds__(IPA_BLK) void k_ipa_round(u32 round, u32 m, const u
     if (round > 1) {
         // u, u^-1 of the previous round were produced by k_ipa_challenge (one lane per proof, its own tiny launch, so that
         // this 256-lane block is never resident while a single lane hashes and inverts)
-        const sc u = ld_sc(&ms[MS_UJ]), ui = ld_sc(&ms[MS_UJI]);
+        // u R, u^-1 R: products with them are single Montgomery multiplications, x * (u R) * R^-1 = x u
+        const sc u = sc_to_mont(ld_sc(&ms[MS_UJ])), ui = sc_to_mont(ld_sc(&ms[MS_UJI]));
         const u32 n2 = 2 * n;  // half length of the previous round = current full length
         // fold a, b: a'[i] = a[i] u + u^-1 a[n2+i] ; b'[i] = b[i] u^-1 + u b[n2+i]
         for (u32 i = tid; i < n2; i += IPA_BLK) {
             sc alo = ld_sc(&a[i]), ahi = ld_sc(&a[n2 + i]), blo = ld_sc(&b[i]), bhi = ld_sc(&b[n2 + i]);
-            st_sc(&a[i], sc_add(sc_mul(alo, u), sc_mul(ui, ahi)));
-            st_sc(&b[i], sc_add(sc_mul(blo, ui), sc_mul(u, bhi)));
+            st_sc(&a[i], sc_add(sc_montmul(alo, u), sc_montmul(ui, ahi)));
+            st_sc(&b[i], sc_add(sc_montmul(blo, ui), sc_montmul(u, bhi)));
         }
-        // generator factors: low half of each 2*n2 block took u^-1 (G) / u (H); high half the opposite
+        // generator factors (Montgomery form in, Montgomery form out): low half of each 2*n2 block took u^-1 (G) / u (H); high
+        // half the opposite.  The tail preparation call hands them to the generator-fold MSM, which needs plain scalars.
+        const bool to_plain = lr_all == nullptr;
         for (u32 k = tid; k < 2048; k += IPA_BLK) {
             bool hi = (k & (2 * n2 - 1)) >= n2;
-            st_sc(&g[k], sc_mul(ld_sc(&g[k]), hi ? u : ui));
-            st_sc(&h[k], sc_mul(ld_sc(&h[k]), hi ? ui : u));
+            sc gk = sc_montmul(ld_sc(&g[k]), hi ? u : ui), hk = sc_montmul(ld_sc(&h[k]), hi ? ui : u);
+            st_sc(&g[k], to_plain ? sc_from_mont(gk) : gk);
+            st_sc(&h[k], to_plain ? sc_from_mont(hk) : hk);
         }
         __syncthreads();
     }
@@ -587,25 +593,25 @@ __global__ __launch_bounds__(IPA_BLK) void k_ipa_round(u32 round, u32 m, const u
         const u32 i = k & (2 * n - 1), blk = k / (2 * n);
         const bool hi = i >= n;
         const u32 io = hi ? i - n : i, rank = blk * n + io;
-        sc gk = ld_sc(&g[k]), hk = ld_sc(&h[k]);
+        sc gk = ld_sc(&g[k]), hk = ld_sc(&h[k]);  // Montgomery form: a * (g R) * R^-1 = a g
         if (hi) {
-            st_sc(&L[rank], sc_mul(ld_sc(&a[io]), gk));            // a_L[io] * G_R
-            st_sc(&R[1024 + rank], sc_mul(ld_sc(&b[io]), hk));     // b_L[io] * H_R
+            st_sc(&L[rank], sc_montmul(ld_sc(&a[io]), gk));            // a_L[io] * G_R
+            st_sc(&R[1024 + rank], sc_montmul(ld_sc(&b[io]), hk));     // b_L[io] * H_R
         } else {
-            st_sc(&R[rank], sc_mul(ld_sc(&a[n + io]), gk));        // a_R[io] * G_L
-            st_sc(&L[1024 + rank], sc_mul(ld_sc(&b[n + io]), hk)); // b_R[io] * H_L
+            st_sc(&R[rank], sc_montmul(ld_sc(&a[n + io]), gk));        // a_R[io] * G_L
+            st_sc(&L[1024 + rank], sc_montmul(ld_sc(&b[n + io]), hk)); // b_R[io] * H_L
         }
     }
     for (u32 i = tid; i < n; i += IPA_BLK) {
         sc alo = ld_sc(&a[i]), ahi = ld_sc(&a[n + i]), blo = ld_sc(&b[i]), bhi = ld_sc(&b[n + i]);
-        c[0] = sc_add(c[0], sc_mul(alo, bhi));
-        c[1] = sc_add(c[1], sc_mul(ahi, blo));
+        c[0] = sc_add(c[0], sc_montmul(alo, bhi));  // sums of x y R^-1: one conversion after the block sum
+        c[1] = sc_add(c[1], sc_montmul(ahi, blo));
     }
     block_sum_sc<2, IPA_BLK>(c, lds);
     if (tid == 0) {
-        sc w = ld_sc(&ms[MS_W]);  // Q = w B, so c * Q = (c w) B
-        st_sc(&L[2048], sc_mul(c[0], w));
-        st_sc(&R[2048], sc_mul(c[1], w));
+        const sc wr = sc_montmul(sc_to_mont(ld_sc(&ms[MS_W])), sc_rr());  // w R^2: (c R^-1) * (w R^2) * R^-1 = c w.  Q = w B, c * Q = (c w) B
+        st_sc(&L[2048], sc_montmul(c[0], wr));
+        st_sc(&R[2048], sc_montmul(c[1], wr));
     }
 }
 
