@@ -411,18 +411,19 @@ __global__ __launch_bounds__(POLY_BLK) void k_poly(u32 n1, const sc* __restrict_
         st_sc(&r0o[(size_t)p * n1 + i], r0);
         st_sc(&r1o[(size_t)p * n1 + i], r1);
         st_sc(&r3o[(size_t)p * n1 + i], r3);
-        t[0] = sc_add(t[0], sc_mul(l1, r0));
-        t[1] = sc_add(t[1], sc_add(sc_mul(l1, r1), sc_mul(l2, r0)));
-        t[2] = sc_add(t[2], sc_add(sc_mul(l2, r1), sc_mul(l3, r0)));
-        t[3] = sc_add(t[3], sc_add(sc_mul(l1, r3), sc_mul(l3, r1)));
-        t[4] = sc_add(t[4], sc_mul(l2, r3));
-        t[5] = sc_add(t[5], sc_mul(l3, r3));
+        // the six sums collect x y R^-1 (single Montgomery multiplications); one conversion each after the block sum
+        t[0] = sc_add(t[0], sc_montmul(l1, r0));
+        t[1] = sc_add(t[1], sc_add(sc_montmul(l1, r1), sc_montmul(l2, r0)));
+        t[2] = sc_add(t[2], sc_add(sc_montmul(l2, r1), sc_montmul(l3, r0)));
+        t[3] = sc_add(t[3], sc_add(sc_montmul(l1, r3), sc_montmul(l3, r1)));
+        t[4] = sc_add(t[4], sc_montmul(l2, r3));
+        t[5] = sc_add(t[5], sc_montmul(l3, r3));
     }
     block_sum_sc<6, POLY_BLK>(t, lds);
     if (threadIdx.x == 0) {
         sc* ms = misc + (size_t)p * MS_COUNT;
 #pragma unroll
-        for (int k = 0; k < 6; k++) st_sc(&ms[MS_T1 + k], t[k]);
+        for (int k = 0; k < 6; k++) st_sc(&ms[MS_T1 + k], sc_to_mont(t[k]));  // (t R^-1) R^2 R^-1 = t
     }
 }
 
@@ -508,10 +509,12 @@ __global__ void k_lrvec(u32 B, u32 n1, const sc* __restrict__ l1, const sc* __re
     sc x = ld_sc(&ms[MS_X]);
     sc av, bv, gv;
     if (i < n1) {
-        sc x2 = sc_mul(x, x), x3 = sc_mul(x2, x);
+        // x R, x^2 R, x^3 R: each product with a coefficient is then one Montgomery multiplication
+        const sc xr = sc_to_mont(x), x2r = sc_montmul(xr, xr), x3r = sc_montmul(x2r, xr);
         sc l2 = ld_sc(&ao1[(size_t)p * (1 + n1) + 1 + i]), l3 = ld_sc(&s1[(size_t)p * (1 + 2 * n1) + 1 + i]);
-        av = sc_add(sc_add(sc_mul(ld_sc(&l1[(size_t)p * n1 + i]), x), sc_mul(l2, x2)), sc_mul(l3, x3));
-        bv = sc_add(sc_add(ld_sc(&r0[(size_t)p * n1 + i]), sc_mul(ld_sc(&r1[(size_t)p * n1 + i]), x)), sc_mul(ld_sc(&r3[(size_t)p * n1 + i]), x3));
+        av = sc_add(sc_add(sc_montmul(ld_sc(&l1[(size_t)p * n1 + i]), xr), sc_montmul(l2, x2r)), sc_montmul(l3, x3r));
+        bv = sc_add(sc_add(ld_sc(&r0[(size_t)p * n1 + i]), sc_montmul(ld_sc(&r1[(size_t)p * n1 + i]), xr)),
+                    sc_montmul(ld_sc(&r3[(size_t)p * n1 + i]), x3r));
         gv = sc_one();
     } else {
         av = sc_zero();
