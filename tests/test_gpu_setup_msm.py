@@ -100,3 +100,25 @@ def test_msm_linearity_large_batch(ctx, bbp):
     d0 = rs.pt_add(pts[1], rs.pt_neg(pts[0]))
     for b in range(2, B):
         assert rs.pt_eq(rs.pt_add(pts[b], rs.pt_neg(pts[b - 1])), d0), b
+
+
+def test_msm_dev_noncanonical_scalars_do_not_fault(ctx, bbp):
+    """include/bbp.h: the device-pointer variant cannot screen scalars; non-canonical ones give an unspecified point but must
+    never fault (row indices stay inside the table whatever the bits are).  All-ones words are the worst case for the recoding
+    (every window carries); canonical rows in the same call must still be exact."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n_terms, B = 301, 4  # layout 0: B~ + m G's + m H's
+    rnd = random.Random(5)
+    good = [rnd.randrange(L) for _ in range(n_terms)]
+    rows = [good, [2**256 - 1] * n_terms, [L + i for i in range(n_terms)], [rnd.getrandbits(256) for _ in range(n_terms)]]
+    buf = b"".join(v.to_bytes(32, "little") for row in rows for v in row)
+    d_in = torch.frombuffer(bytearray(buf), dtype=torch.uint8).to(dev)
+    d_out = torch.zeros(B * 32, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    ctx.msm_batch_dev(B, n_terms, d_in.data_ptr(), bbp.LAYOUT_BLIND_G_H, d_out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    out = bytes(d_out.cpu().numpy().tobytes())
+    assert out[:32] == rs.encode(rs.msm(good, _bases(bbp.LAYOUT_BLIND_G_H, n_terms, bbp)))
+    for b in range(1, B):
+        assert rs.decode(out[32 * b:32 * b + 32]) is not None  # still a valid group element
