@@ -11,7 +11,7 @@
 // no doublings anywhere.  The hot loop is instruction-issue bound (measured: serving all rows from cache changes its time
 // by 7 %), so fewer additions and no unpacking are what count; the 134 MB of rows are HBM/MALL resident.
 //
-// One workgroup owns one MSM, in two kernels (k_msm_sort: 256 thin lanes, k_msm_acc: 128 fat lanes):
+// One workgroup owns one MSM, in two kernels (k_msm_sort: 1024 thin lanes, k_msm_acc: 128 fat lanes):
 //   A. NAF digits of every scalar -> LDS histogram over bucket (|d| + 1) / 2
 //   B. exclusive scan -> bucket offsets
 //   C. counting-sort scatter of (row index, sign) into the MSM's HBM scratch slice; bucket end offsets to HBM
@@ -134,7 +134,11 @@ __device__ __noinline__ void ge_dbl_nc(ge& r, const ge& a) { r = ge_dbl(a); }
 // MSMs per round cost far more than working with the 32 + 32 explicit folded generators F_G[i] = sum_{k = i mod 32} g[k] G[k]
 // (F_H likewise); one Pippenger pass per side computes all 32 sums, a running-sum fold per class (4 lanes x 32 keys) ends it.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int SORT_T = 256;
+#ifndef BBP_SORT_T
+#define BBP_SORT_T 1024
+#endif
+constexpr int SORT_T = BBP_SORT_T;  // lanes of the sort workgroup: the kernel is latency-bound, so one scalar or two per lane (measured on
+                                    // the 1024-proof batch: 256 lanes 64.1 ms, 512 lanes 62.4 ms, 1024 lanes 61.2 ms per batch)
 template <int MODE> struct msm_geom;
 template <> struct msm_geom<0> { static constexpr int K = MSM_K, NAF = MSM_NAF, W = MSM_W; };
 template <> struct msm_geom<1> { static constexpr int K = FOLD_K, NAF = FOLD_NAF, W = FOLD_W; };
