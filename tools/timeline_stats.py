@@ -10,7 +10,7 @@ with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
         rows.append((r['Kernel_Name'].split('(')[0].replace('void ', '').replace('bbp::', ''), int(r['Start_Timestamp']), int(r['End_Timestamp'])))
 rows.sort(key=lambda r: r[1])
-opens = [r for r in rows if r[0] == 'k_tr_open']
+opens = [r for r in rows if r[0] in ('k_tr_open', 'k_open_serial')]
 a, b = opens[-4][1], opens[-1][1]  # three steady-state steps
 steps = 3
 span = (b - a) / 1e6
