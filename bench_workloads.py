@@ -172,7 +172,8 @@ class ProveWorkload(_Base):
         self.alg_bytes_per_step = batch * (ref_terms * 160 + 32 * ((4 + items) + 8 + 22))
         # what the engine's MSM kernels actually add (fold-free IPA: rounds 1-6 are 2 x 2049-term MSMs over the original generators,
         # then one composite-bucket pass over all 4096 generators; the tail rounds are variable-base work outside the MSM kernels)
-        engine_terms = commit_terms + 6 * 2 * 2049
+        # (round 1 walks the 2048 - n1 zero-padded multipliers' common-scalar terms of L as ONE term on a precomputed sum)
+        engine_terms = commit_terms + 6 * 2 * 2049 - max(2048 - n1 - 1, 0)
         self.row_additions_per_step = batch * (engine_terms * NAF12_DIGITS + 4096 * NAF9_DIGITS)
         self.dominant_launches_per_step = 3 + 6 + 1
         self.measured_traffic_bytes = None  # set from profiles/ (rocprofv3 PMC passes) for the B = 1024, N = 8 configuration

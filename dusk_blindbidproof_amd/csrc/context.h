@@ -33,6 +33,12 @@ constexpr int FOLD_NAF = 9;                // width-9 NAF: odd digits |d| < 256
 constexpr int FOLD_W = 29;                 // most digits per scalar
 constexpr int FOLD_M = 128;                // buckets per class
 constexpr int FOLD_K = FOLD_CLS * FOLD_M;  // 4096 composite buckets
+// Extra table bases (internal, after the 4098 public ones): PAD_BASE0 + N - 1 = sum_{k = 418 + 3N}^{1023} H[k], the generators
+// that the first IPA round multiplies by ONE common scalar (the zero-padded multipliers n1 = 1442 + 3N .. 2047 contribute
+// b[i] h[i - 1024] = -y^1024 for every i): 582 table-row walks become one (prover.hip k_ipa_round, circuit_get).
+constexpr int PAD_BASES = 202;                             // one per list length N = 1..202
+constexpr unsigned PAD_BASE0 = BBP_NUM_BASES;
+constexpr unsigned TAB_BASES = BBP_NUM_BASES + PAD_BASES;  // bases with rows in ptable
 constexpr int GE_WORDS = sizeof(ge) / 4;  // 40: a point in registers / LDS / scratch
 
 struct DevBuf {
@@ -66,8 +72,8 @@ struct bbp_ctx {
     bool ev_last_valid = false;
     std::string err;
     // resident tables
-    bbp::ge* gens = nullptr;           // [BBP_NUM_BASES] extended points: B_blinding, G[2048], H[2048], B
-    bbp::niels_row* ptable = nullptr;      // [BBP_NUM_BASES * MSM_POS] affine cached 2^b * P_i, 128-byte limb rows (134 MB)
+    bbp::ge* gens = nullptr;           // [TAB_BASES] extended points: B_blinding, G[2048], H[2048], B, then the PAD_BASES range sums
+    bbp::niels_row* ptable = nullptr;      // [TAB_BASES * MSM_POS] affine cached 2^b * P_i, 128-byte limb rows (141 MB)
     bbp::ge* btab = nullptr;               // [32] m * 2^(64 k) * B, m = 1..8, k = 0..3 (prover.hip tail rounds)
     bbp::niels_packed* comb = nullptr;     // [2][64][8] radix-16 comb for B and B_blinding (small commits)
     bbp::sc* mimc_c = nullptr;         // [90]

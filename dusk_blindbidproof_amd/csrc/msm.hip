@@ -77,7 +77,7 @@ __device__ __forceinline__ ge xch_get(const u32* xch) {
 // one 128-byte row, one cache line.  The index is clamped: a corrupted scratch entry must never turn into an out-of-bounds
 // gather (a GPU fault here takes the whole node down); one v_min_u32 per ~1400-instruction iteration.
 __device__ __forceinline__ niels_row load_row(const niels_row* __restrict__ tab, u32 entry) {
-    u32 row = min(entry & 0x7fffffffu, (u32)(BBP_NUM_BASES * MSM_POS - 1));
+    u32 row = min(entry & 0x7fffffffu, (u32)(TAB_BASES * MSM_POS - 1));
 #ifdef BBP_EXP_ROWMASK  // experiment (wrong results): alias all gathers onto a cache-resident slice of the table
     row &= BBP_EXP_ROWMASK;
 #endif

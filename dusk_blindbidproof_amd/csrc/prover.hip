@@ -550,7 +550,7 @@ __global__ void k_ipa_challenge(u32 B, u32 prev_round, u32 m, const u32* __restr
 //   round > 1: lane 0 first absorbs the previous L, R, draws u, inverts it; everyone folds a, b and updates g, h.
 //   then: c_L, c_R and the scalars of this round's L and R over the ORIGINAL generators.
 constexpr int IPA_BLK = 256;
-__global__ __launch_bounds__(IPA_BLK) void k_ipa_round(u32 round, u32 m, const u32* __restrict__ enc, merlin_transcript* __restrict__ tr,
+__global__ __launch_bounds__(IPA_BLK) void k_ipa_round(u32 round, u32 n1, const u32* __restrict__ enc, merlin_transcript* __restrict__ tr,
                                                         sc* __restrict__ misc, sc* __restrict__ a_all, sc* __restrict__ b_all,
                                                         sc* __restrict__ g_all, sc* __restrict__ h_all, sc* __restrict__ lr_all) {
     BBP_THIN_PRIO();
@@ -562,7 +562,6 @@ __global__ __launch_bounds__(IPA_BLK) void k_ipa_round(u32 round, u32 m, const u
     const u32 n = 1024u >> (round - 1);
     (void)enc;
     (void)tr;
-    (void)m;
     (void)bc;
     if (round > 1) {
         // u, u^-1 of the previous round were produced by k_ipa_challenge (one lane per proof, its own tiny launch, so that
@@ -602,7 +601,10 @@ __global__ __launch_bounds__(IPA_BLK) void k_ipa_round(u32 round, u32 m, const u
             st_sc(&R[1024 + rank], sc_montmul(ld_sc(&b[io]), hk));     // b_L[io] * H_R
         } else {
             st_sc(&R[rank], sc_montmul(ld_sc(&a[n + io]), gk));        // a_R[io] * G_L
-            st_sc(&L[1024 + rank], sc_montmul(ld_sc(&b[n + io]), hk)); // b_R[io] * H_L
+            // b_R[io] * H_L.  Round 1: for the zero-padded multipliers i = n + io >= n1 this product is -y^1024 whatever io is;
+            // only the first of them keeps it, on the precomputed sum of those H's (PAD_BASE0, circuit_get), the rest are zero
+            const bool dup = round == 1 && n + io > n1;
+            st_sc(&L[1024 + rank], dup ? sc_zero() : sc_montmul(ld_sc(&b[n + io]), hk));
         }
     }
     for (u32 i = tid; i < n; i += IPA_BLK) {
@@ -924,6 +926,9 @@ int32_t circuit_get(bbp_ctx* ctx, uint32_t n_items, const CircuitDev** out) {
             R[1024 + rank] = BBP_BASE_H0 + k_hi;
         }
         L[2048] = R[2048] = BBP_BASE_B;
+        // round 1: the padded multipliers' terms of L share one scalar; their first slot carries it on the range-sum base, the
+        // others carry zero (k_ipa_round)
+        if (r == 1 && c.n_mul < 2048) L[1024 + (c.n_mul - 1024)] = PAD_BASE0 + n_items - 1;
         ipa.insert(ipa.end(), L.begin(), L.end());
         ipa.insert(ipa.end(), R.begin(), R.end());
     }
@@ -1134,7 +1139,7 @@ static int32_t prove_heavy(bbp_ctx* ctx, const CircuitDev& c, const BatchDev& bd
     const u32 tail_from = (u32)ctx->tail_round;  // FOLD_ROUND (7), or 12 = never leave the fixed-base formulation
     for (u32 r = 1; r <= 11 && r < tail_from; r++) {
         if (r > 1) LAUNCH(ctx, TAG_TRANSCRIPT, k_ipa_challenge, cdiv(B, 64), 64, s, B, r - 1, m, bd.enc, bd.tr, bd.misc);
-        LAUNCH(ctx, TAG_IPA_SCALARS, k_ipa_round, B, IPA_BLK, s, r, m, bd.enc, bd.tr, bd.misc, bd.a, bd.b, bd.g, bd.h, bd.lr);
+        LAUNCH(ctx, TAG_IPA_SCALARS, k_ipa_round, B, IPA_BLK, s, r, n1, bd.enc, bd.tr, bd.misc, bd.a, bd.b, bd.g, bd.h, bd.lr);
         if ((rc = msm_launch(ctx, 2 * B, 2049, (const u32*)bd.lr, c.idx_ipa + (size_t)(r - 1) * 2 * 2049, bd.lrpts, s, 2, slot))) return rc;
         LAUNCH(ctx, TAG_ENCODE, k_encode_strided, cdiv(2 * B, 64), 64, s, 2 * B, 2u, bd.lrpts, 2u, bd.enc, encw, 8 * (m + 8 + 2 * (r - 1)));
     }
@@ -1145,7 +1150,7 @@ static int32_t prove_heavy(bbp_ctx* ctx, const CircuitDev& c, const BatchDev& bd
         if ((rc = dev_reserve(ctx, vt, (size_t)B * 2 * FOLD_CLS * TAIL_TAB * sizeof(ge)))) return rc;
         ge* ftab = static_cast<ge*>(vt.p);
         LAUNCH(ctx, TAG_TRANSCRIPT, k_ipa_challenge, cdiv(B, 64), 64, s, B, tail_from - 1, m, bd.enc, bd.tr, bd.misc);
-        LAUNCH(ctx, TAG_IPA_SCALARS, k_ipa_round, B, IPA_BLK, s, tail_from, m, bd.enc, bd.tr, bd.misc, bd.a, bd.b, bd.g, bd.h, (sc*)nullptr);
+        LAUNCH(ctx, TAG_IPA_SCALARS, k_ipa_round, B, IPA_BLK, s, tail_from, n1, bd.enc, bd.tr, bd.misc, bd.a, bd.b, bd.g, bd.h, (sc*)nullptr);
         if ((rc = fold_generators_launch(ctx, B, bd.g, bd.h, bd.fpts, s, slot))) return rc;
         LAUNCH(ctx, TAG_VARBASE, k_tail_init, cdiv(B * FOLD_CLS, 64), 64, s, B, bd.g, bd.h);
         LAUNCH(ctx, TAG_VARBASE, k_tail_tables, cdiv(B * 2 * FOLD_CLS, 64), 64, s, B * 2 * FOLD_CLS, bd.fpts, ftab);

@@ -28,11 +28,22 @@ __global__ void k_derive_generators(const u32* __restrict__ uniform, ge* __restr
     gens[i] = ge_from_uniform_words(w);  // 0: B_blinding, 1..2048: G, 2049..4096: H
 }
 
+// PAD_BASE0 + N - 1 = H[418 + 3N] + ... + H[1023] (context.h): one lane walks the suffix sums down
+__global__ void k_pad_sums(ge* __restrict__ gens) {
+    if (blockIdx.x || threadIdx.x) return;
+    ge acc = ge_identity();
+    gens[PAD_BASE0 + PAD_BASES - 1] = acc;  // N = 202: no padded multiplier, empty range (never used with a non-zero scalar)
+    for (int k = 1023; k >= 421; k--) {
+        acc = ge_add(acc, gens[BBP_BASE_H0 + k]);
+        if ((k - 418) % 3 == 0) gens[PAD_BASE0 + (k - 418) / 3 - 1] = acc;
+    }
+}
+
 // thread (i, c): rows 16c .. 16c+15 of generator i: table[i*256 + b] = affine cached form of 2^b * gens[i]
 constexpr int PT_CHUNK = 16;
 __global__ void k_build_ptable(const ge* __restrict__ gens, niels_row* __restrict__ table) {
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= BBP_NUM_BASES * (MSM_POS / PT_CHUNK)) return;
+    if (t >= TAB_BASES * (MSM_POS / PT_CHUNK)) return;
     const u32 i = t / (MSM_POS / PT_CHUNK), c = t % (MSM_POS / PT_CHUNK);
     ge p = gens[i];
     for (u32 k = 0; k < c * PT_CHUNK; k++) p = ge_dbl(p);
@@ -131,14 +142,16 @@ extern "C" int32_t bbp_init(int32_t device, bbp_ctx** out) {
     u32* d_uniform = nullptr;
     BBP_HIP_TRY(ctx, hipMalloc(&d_uniform, uniform.size()));
     BBP_HIP_TRY(ctx, hipMemcpyAsync(d_uniform, uniform.data(), uniform.size(), hipMemcpyHostToDevice, ctx->stream));
-    BBP_HIP_TRY(ctx, hipMalloc(&ctx->gens, sizeof(ge) * BBP_NUM_BASES));
-    BBP_HIP_TRY(ctx, hipMalloc(&ctx->ptable, sizeof(niels_row) * (size_t)BBP_NUM_BASES * MSM_POS));
+    BBP_HIP_TRY(ctx, hipMalloc(&ctx->gens, sizeof(ge) * TAB_BASES));
+    BBP_HIP_TRY(ctx, hipMalloc(&ctx->ptable, sizeof(niels_row) * (size_t)TAB_BASES * MSM_POS));
     BBP_HIP_TRY(ctx, hipMalloc(&ctx->comb, sizeof(niels_packed) * 2 * 64 * 8));
     BBP_HIP_TRY(ctx, hipMalloc(&ctx->mimc_c, sizeof(sc) * BBP_MIMC_ROUNDS));
     BBP_HIP_TRY(ctx, hipMemcpyAsync(ctx->mimc_c, ctx->mimc_host.data(), 32 * BBP_MIMC_ROUNDS, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_derive_generators, dim3((BBP_NUM_BASES + 63) / 64), dim3(64), 0, ctx->stream, d_uniform, ctx->gens);
     BBP_HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_build_ptable, dim3((BBP_NUM_BASES * (MSM_POS / PT_CHUNK) + 63) / 64), dim3(64), 0, ctx->stream, ctx->gens, ctx->ptable);
+    hipLaunchKernelGGL(k_pad_sums, dim3(1), dim3(64), 0, ctx->stream, ctx->gens);
+    BBP_HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_build_ptable, dim3((TAB_BASES * (MSM_POS / PT_CHUNK) + 63) / 64), dim3(64), 0, ctx->stream, ctx->gens, ctx->ptable);
     BBP_HIP_TRY(ctx, hipGetLastError());
     if (int32_t rc = tail_btab_build(ctx)) return rc;
     hipLaunchKernelGGL(k_build_comb, dim3(2), dim3(64), 0, ctx->stream, ctx->gens, ctx->comb);
