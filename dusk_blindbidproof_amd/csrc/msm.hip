@@ -183,18 +183,29 @@ __global__ __launch_bounds__(SORT_T) void k_msm_sort(const u32* __restrict__ sca
     {
         u32 local = 0;
         for (int r = 1; r <= G; r++) local += cursor[tid * G + r];
-        part[tid] = local;
+        // block-wide exclusive scan of `local`: inclusive scan inside each wavefront by shuffles, wave totals through LDS
+        // (a single lane looping over 1024 partial sums used to cost a fifth of this kernel)
+        const int lane = tid & 63, wave = tid >> 6;
+        u32 incl = local;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const u32 up = (u32)__shfl_up((int)incl, d, 64);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) part[wave] = incl;
         __syncthreads();
-        if (tid == 0) {
-            u32 run = 0;
-            for (int t = 0; t < SORT_T; t++) {
-                u32 v = part[t];
-                part[t] = run;
-                run += v;
+        if (tid < 64) {
+            constexpr int NW = SORT_T / 64;
+            u32 v = tid < NW ? part[tid] : 0u, sc_ = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const u32 up = (u32)__shfl_up((int)sc_, d, 64);
+                if (tid >= d) sc_ += up;
             }
+            if (tid < NW) part[tid] = sc_ - v;  // exclusive prefix of the wave totals
         }
         __syncthreads();
-        u32 base = part[tid];
+        u32 base = part[wave] + incl - local;
         for (int r = 1; r <= G; r++) {
             const u32 c = cursor[tid * G + r];
             cursor[tid * G + r] = base;
