@@ -13,6 +13,14 @@ After the timed region the default run also measures the other two workloads for
 Each rank works on its own B proofs (independent units, no data-path collective; weak scaling); the only collective is the
 final gather of proof records / flags to rank 0.  cpu_baseline (rank 0, N=1 only) times the C oracle on the host cores.
 """
+import os
+
+# The engine keeps four HIP streams busy per GPU (the caller's, the opening stage's, two more heavy-stage slices) -- HIP's default
+# number of hardware queues.  Any other stream used before it (torch.distributed's RCCL stream in the multi-rank run) makes
+# two of them share a queue and serialise: measured 84.5 vs 61.6 ms per batch (tools/hwq_probe.py).  Must be set before the HIP
+# runtime initialises, i.e. before the first torch.cuda call.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import argparse
 import json
 import os
