@@ -261,6 +261,8 @@ void k_msm_acc(const niels_row* __restrict__ ptable, const u32* __restrict__ sor
 #ifdef BBP_MSM_PROF
     const unsigned long long clk0 = clock64();
 #endif
+    u32 k_first = 0;         // bucket holding this lane's first entry
+    bool inside = false;     // the chunk starts strictly inside it: its leading partial sum went to psum[tid]
     if (c0 < c1) {
         // bucket containing entry c0: smallest k with cursor[k] > c0
         u32 lo = 1, hi = K;
@@ -269,7 +271,9 @@ void k_msm_acc(const niels_row* __restrict__ ptable, const u32* __restrict__ sor
             if (cursor[mid] > c0) hi = mid; else lo = mid + 1;
         }
         u32 k = lo, kend = cursor[k];
-        ge* dest = (cursor[k - 1] < c0) ? &psum[tid] : &bsum[k - 1];
+        k_first = lo;
+        inside = cursor[k - 1] < c0;
+        ge* dest = inside ? &psum[tid] : &bsum[k - 1];
         ge acc = ge_identity();
         // software pipeline, two deep: the entry index is fetched two iterations ahead and the 128-byte table row one
         // iteration ahead, so neither load is waited for before a full mixed addition (~1300 instructions) has run
@@ -300,22 +304,31 @@ void k_msm_acc(const niels_row* __restrict__ ptable, const u32* __restrict__ sor
     __syncthreads();
     MSM_PROF_MARK(3);
 
+    // P. the chunk-leading partial sums go into their buckets, ONE addition per lane for the whole wave (folded into the
+    //    bucket loop below they cost an addition in nearly every one of its G steps: some lane of the wave always had one).
+    //    When several consecutive chunks start inside the same (heavy) bucket, the last of them adds the whole run.
+    {
+        const bool last_of_run = inside && !(c1 < E && c1 > cursor[k_first - 1] && c1 < cursor[k_first]);
+        if (last_of_run) {
+            ge part = psum[tid];
+            for (int u = tid - 1; u >= 0; u--) {  // earlier chunks that also start strictly inside this bucket (skewed inputs only)
+                const u32 cu = (u32)(((u64)u * E) / MSM_T), cu1 = (u32)(((u64)(u + 1) * E) / MSM_T);
+                if (cu <= cursor[k_first - 1]) break;
+                if (cu1 > cu) ge_add_nc(part, part, psum[u]);
+            }
+            ge head = bsum[k_first - 1];
+            ge_add_nc(head, head, part);
+            bsum[k_first - 1] = head;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+
     // D2. running-sum fold over this lane's G buckets (high to low), all lanes in lockstep
     ge running = ge_identity(), total = ge_identity();
     for (int r = G; r >= 1; r--) {
         const u32 k = tid * G + r;
-        const u32 kend = cursor[k], kbeg = cursor[k - 1];
-        if (kbeg != kend) {
-            ge_add_nc(running, running, bsum[k - 1]);
-            // chunks that START strictly inside this bucket carry a partial sum for it
-            u32 t = (u32)(((u64)kbeg * MSM_T) / E);
-            for (; t < MSM_T; t++) {
-                const u32 ct = (u32)(((u64)t * E) / MSM_T);
-                if (ct >= kend) break;
-                const u32 ct1 = (u32)(((u64)(t + 1) * E) / MSM_T);
-                if (ct > kbeg && ct1 > ct) ge_add_nc(running, running, psum[t]);
-            }
-        }
+        if (cursor[k] != cursor[k - 1]) ge_add_nc(running, running, bsum[k - 1]);
         ge_add_nc(total, total, running);
     }
     MSM_PROF_MARK(4);
