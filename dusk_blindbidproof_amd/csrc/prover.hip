@@ -683,7 +683,8 @@ __device__ ge ge_double_scalarmul(const sc& s1, const ge& P1, const sc& s2, cons
 // over such a table is 60 doublings + 64 additions (signed radix-16 digits, four 64-bit pieces sharing the doublings) instead of
 // 252 + 64 + 7, and the tables of the 64 materialised generators are built once and used by all five tail rounds.
 constexpr int TAIL_TAB = 32;
-__global__ void k_tail_tables(u32 count, const ge* __restrict__ pts, ge* __restrict__ tab) {
+// (64-lane workgroups and a 2-3 waves/SIMD register budget: with the default 128-VGPR cap this kernel spilled 216 registers)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 3))) void k_tail_tables(u32 count, const ge* __restrict__ pts, ge* __restrict__ tab) {
     BBP_THIN_PRIO();
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= count) return;
