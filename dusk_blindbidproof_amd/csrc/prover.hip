@@ -32,6 +32,11 @@ namespace bbp {
 // slice's two fat (older, issue-bound) accumulation waves they would crawl.  Raised wave priority lets them take the issue
 // slots they need -- a few percent of the SIMD -- and get out of the way.
 #define BBP_THIN_PRIO() __builtin_amdgcn_s_setprio(3)
+// one-lane-per-item kernels launched with 64-thread workgroups: say so, or the compiler assumes 1024-thread workgroups, caps
+// them at 128 VGPRs and spills (k_tr_ux 74 registers, k_vtranscript 64, k_powers 34)
+#ifndef BBP_LANE_KERNEL
+#define BBP_LANE_KERNEL __launch_bounds__(64)
+#endif
 
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -178,7 +183,7 @@ __device__ ge comb_mul_add(ge acc, const niels_packed* __restrict__ comb_base, c
 }
 
 // commitment c of proof p: values[p*stride_v + c], blindings[p*stride_b + c] -> out[p*out_stride + c]
-__global__ void k_commit(u32 count, u32 per_proof, const sc* __restrict__ values, const sc* __restrict__ blindings, u32 stride_v,
+__global__ BBP_LANE_KERNEL void k_commit(u32 count, u32 per_proof, const sc* __restrict__ values, const sc* __restrict__ blindings, u32 stride_v,
                          u32 stride_b, const niels_packed* __restrict__ comb, ge* __restrict__ out, u32 out_stride) {
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= count) return;
@@ -201,7 +206,7 @@ int32_t commit_launch(bbp_ctx* ctx, u32 count, const sc* values, const sc* blind
 }
 
 // encode `per_proof` points per proof from a strided point array into a strided encoding array
-__global__ void k_encode_strided(u32 count, u32 per_proof, const ge* __restrict__ pts, u32 pts_stride, u32* __restrict__ enc,
+__global__ BBP_LANE_KERNEL void k_encode_strided(u32 count, u32 per_proof, const ge* __restrict__ pts, u32 pts_stride, u32* __restrict__ enc,
                                  u32 enc_stride_words, u32 enc_off_words) {
     BBP_THIN_PRIO();
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -292,7 +297,7 @@ __global__ void k_load_blindings(u32 B, u32 m, const u8* __restrict__ entropy, s
     st_sc(&vb_all[(size_t)p * m + i], sc_reduce256(w));
 }
 
-__global__ void k_tr_yz(u32 B, u32 m, const u32* __restrict__ enc, merlin_transcript* __restrict__ tr, sc* __restrict__ misc) {
+__global__ BBP_LANE_KERNEL void k_tr_yz(u32 B, u32 m, const u32* __restrict__ enc, merlin_transcript* __restrict__ tr, sc* __restrict__ misc) {
     BBP_THIN_PRIO();
     u32 p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= B) return;
@@ -316,7 +321,7 @@ __global__ void k_tr_yz(u32 B, u32 m, const u32* __restrict__ enc, merlin_transc
 }
 
 // out[p][e] = base[p]^e for e in [0, count): one lane per chunk of 32 exponents
-__global__ void k_powers(u32 B, u32 count, const sc* __restrict__ misc, int slot, sc* __restrict__ out, u32 out_stride) {
+__global__ BBP_LANE_KERNEL void k_powers(u32 B, u32 count, const sc* __restrict__ misc, int slot, sc* __restrict__ out, u32 out_stride) {
     BBP_THIN_PRIO();
     const u32 chunks = (count + 31) / 32;
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -427,7 +432,7 @@ __global__ __launch_bounds__(POLY_BLK) void k_poly(u32 n1, const sc* __restrict_
     }
 }
 
-__global__ void k_tr_tblind(u32 B, merlin_transcript* __restrict__ rng, sc* __restrict__ misc) {
+__global__ BBP_LANE_KERNEL void k_tr_tblind(u32 B, merlin_transcript* __restrict__ rng, sc* __restrict__ misc) {
     BBP_THIN_PRIO();
     u32 p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= B) return;
@@ -442,7 +447,7 @@ __global__ void k_tr_tblind(u32 B, merlin_transcript* __restrict__ rng, sc* __re
 }
 
 // T_k = t_k B + tb_k B~ for k in {1,3,4,5,6}: one lane per (proof, k)
-__global__ void k_commit_T(u32 B, const sc* __restrict__ misc, const niels_packed* __restrict__ comb, ge* __restrict__ pts, u32 pts_stride, u32 m) {
+__global__ BBP_LANE_KERNEL void k_commit_T(u32 B, const sc* __restrict__ misc, const niels_packed* __restrict__ comb, ge* __restrict__ pts, u32 pts_stride, u32 m) {
     BBP_THIN_PRIO();
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B * 5) return;
@@ -454,7 +459,7 @@ __global__ void k_commit_T(u32 B, const sc* __restrict__ misc, const niels_packe
     pts[(size_t)p * pts_stride + m + 3 + k] = acc;
 }
 
-__global__ void k_tr_ux(u32 B, u32 m, u32 n1, const u32* __restrict__ enc, const sc* __restrict__ wv, const sc* __restrict__ vb,
+__global__ BBP_LANE_KERNEL void k_tr_ux(u32 B, u32 m, u32 n1, const u32* __restrict__ enc, const sc* __restrict__ wv, const sc* __restrict__ vb,
                         const sc* __restrict__ ai1, const sc* __restrict__ ao1, const sc* __restrict__ s1,
                         merlin_transcript* __restrict__ tr, sc* __restrict__ misc) {
     BBP_THIN_PRIO();
@@ -530,7 +535,7 @@ __global__ void k_lrvec(u32 B, u32 n1, const sc* __restrict__ l1, const sc* __re
 }
 
 // Fiat-Shamir step between IPA rounds: absorb L_j, R_j (j = prev_round), draw u_j, invert it.  One lane per proof.
-__global__ void k_ipa_challenge(u32 B, u32 prev_round, u32 m, const u32* __restrict__ enc, merlin_transcript* __restrict__ tr,
+__global__ BBP_LANE_KERNEL void k_ipa_challenge(u32 B, u32 prev_round, u32 m, const u32* __restrict__ enc, merlin_transcript* __restrict__ tr,
                                 sc* __restrict__ misc) {
     BBP_THIN_PRIO();
     u32 p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -831,7 +836,7 @@ __global__ __launch_bounds__(TAIL_BLK) void k_tail_lr(u32 n, u32 prev_round, u32
     if (j == 0) lrpts[(size_t)p * 2 + side] = q;
 }
 
-__global__ void k_ipa_final(u32 B, u32 m, const u32* __restrict__ enc, merlin_transcript* __restrict__ tr, sc* __restrict__ misc,
+__global__ BBP_LANE_KERNEL void k_ipa_final(u32 B, u32 m, const u32* __restrict__ enc, merlin_transcript* __restrict__ tr, sc* __restrict__ misc,
                             const sc* __restrict__ a_all, const sc* __restrict__ b_all) {
     BBP_THIN_PRIO();
     u32 p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -850,7 +855,7 @@ __global__ void k_ipa_final(u32 B, u32 m, const u32* __restrict__ enc, merlin_tr
 }
 
 // record = R1CSProof::to_bytes (1-phase compact form, A.8) || V[0..4) || V[4..m)
-__global__ void k_assemble(u32 B, u32 m, const u32* __restrict__ enc, const sc* __restrict__ misc, u8* __restrict__ out) {
+__global__ BBP_LANE_KERNEL void k_assemble(u32 B, u32 m, const u32* __restrict__ enc, const sc* __restrict__ misc, u8* __restrict__ out) {
     BBP_THIN_PRIO();
     u32 p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= B) return;
