@@ -552,22 +552,17 @@ __global__ BBP_LANE_KERNEL void k_ipa_challenge(u32 B, u32 prev_round, u32 m, co
 }
 
 // K6: one inner-product round.  n = half length of THIS round (1024 >> (round-1)).
-//   round > 1: lane 0 first absorbs the previous L, R, draws u, inverts it; everyone folds a, b and updates g, h.
+//   round > 1: with u, 1/u of the previous round (k_ipa_challenge) fold a, b and update the factor vectors g, h.
 //   then: c_L, c_R and the scalars of this round's L and R over the ORIGINAL generators.
 constexpr int IPA_BLK = 256;
-__global__ __launch_bounds__(IPA_BLK) void k_ipa_round(u32 round, u32 n1, const u32* __restrict__ enc, merlin_transcript* __restrict__ tr,
-                                                        sc* __restrict__ misc, sc* __restrict__ a_all, sc* __restrict__ b_all,
+__global__ __launch_bounds__(IPA_BLK) void k_ipa_round(u32 round, u32 n1, sc* __restrict__ misc, sc* __restrict__ a_all, sc* __restrict__ b_all,
                                                         sc* __restrict__ g_all, sc* __restrict__ h_all, sc* __restrict__ lr_all) {
     BBP_THIN_PRIO();
     __shared__ u32 lds[2 * 8 * IPA_BLK];
-    __shared__ u32 bc[16];
     const u32 p = blockIdx.x, tid = threadIdx.x;
     sc* ms = misc + (size_t)p * MS_COUNT;
     sc *a = a_all + (size_t)p * 2048, *b = b_all + (size_t)p * 2048, *g = g_all + (size_t)p * 2048, *h = h_all + (size_t)p * 2048;
     const u32 n = 1024u >> (round - 1);
-    (void)enc;
-    (void)tr;
-    (void)bc;
     if (round > 1) {
         // u, u^-1 of the previous round were produced by k_ipa_challenge (one lane per proof, its own tiny launch, so that
         // this 256-lane block is never resident while a single lane hashes and inverts)
@@ -1145,7 +1140,7 @@ static int32_t prove_heavy(bbp_ctx* ctx, const CircuitDev& c, const BatchDev& bd
     const u32 tail_from = (u32)ctx->tail_round;  // FOLD_ROUND (7), or 12 = never leave the fixed-base formulation
     for (u32 r = 1; r <= 11 && r < tail_from; r++) {
         if (r > 1) LAUNCH(ctx, TAG_TRANSCRIPT, k_ipa_challenge, cdiv(B, 64), 64, s, B, r - 1, m, bd.enc, bd.tr, bd.misc);
-        LAUNCH(ctx, TAG_IPA_SCALARS, k_ipa_round, B, IPA_BLK, s, r, n1, bd.enc, bd.tr, bd.misc, bd.a, bd.b, bd.g, bd.h, bd.lr);
+        LAUNCH(ctx, TAG_IPA_SCALARS, k_ipa_round, B, IPA_BLK, s, r, n1, bd.misc, bd.a, bd.b, bd.g, bd.h, bd.lr);
         if ((rc = msm_launch(ctx, 2 * B, 2049, (const u32*)bd.lr, c.idx_ipa + (size_t)(r - 1) * 2 * 2049, bd.lrpts, s, 2, slot))) return rc;
         LAUNCH(ctx, TAG_ENCODE, k_encode_strided, cdiv(2 * B, 64), 64, s, 2 * B, 2u, bd.lrpts, 2u, bd.enc, encw, 8 * (m + 8 + 2 * (r - 1)));
     }
@@ -1156,7 +1151,7 @@ static int32_t prove_heavy(bbp_ctx* ctx, const CircuitDev& c, const BatchDev& bd
         if ((rc = dev_reserve(ctx, vt, (size_t)B * 2 * FOLD_CLS * TAIL_TAB * sizeof(ge)))) return rc;
         ge* ftab = static_cast<ge*>(vt.p);
         LAUNCH(ctx, TAG_TRANSCRIPT, k_ipa_challenge, cdiv(B, 64), 64, s, B, tail_from - 1, m, bd.enc, bd.tr, bd.misc);
-        LAUNCH(ctx, TAG_IPA_SCALARS, k_ipa_round, B, IPA_BLK, s, tail_from, n1, bd.enc, bd.tr, bd.misc, bd.a, bd.b, bd.g, bd.h, (sc*)nullptr);
+        LAUNCH(ctx, TAG_IPA_SCALARS, k_ipa_round, B, IPA_BLK, s, tail_from, n1, bd.misc, bd.a, bd.b, bd.g, bd.h, (sc*)nullptr);
         if ((rc = fold_generators_launch(ctx, B, bd.g, bd.h, bd.fpts, s, slot))) return rc;
         LAUNCH(ctx, TAG_VARBASE, k_tail_init, cdiv(B * FOLD_CLS, 64), 64, s, B, bd.g, bd.h);
         LAUNCH(ctx, TAG_VARBASE, k_tail_tables, cdiv(B * 2 * FOLD_CLS, 64), 64, s, B * 2 * FOLD_CLS, bd.fpts, ftab);
