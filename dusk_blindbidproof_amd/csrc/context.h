@@ -62,6 +62,7 @@ struct bbp_ctx {
     std::map<const void*, int> serial_attr;
     int stagger_mode = 0;  // 0: slices start together, 1: next slice starts after this slice's first MSM, 3: after its third (BBP_STAGGER)
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_open[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    hipEvent_t ev_entry[2] = {nullptr, nullptr};  // caller's stream at entry of a prove call: out_dev is not written before it
     bool ev_done_valid[2] = {false, false}, ev_open_valid[2] = {false, false};
     uint32_t seq = 0;
     int last_par = 0;

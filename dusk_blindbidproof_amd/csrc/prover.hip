@@ -1025,7 +1025,7 @@ int32_t tail_btab_build(bbp_ctx* ctx) {  // called once from bbp_init: the table
 
 static BatchDev batch_view(const BatchDev& bd, const CircuitDev& c, u32 first);
 static int32_t prove_heavy(bbp_ctx* ctx, const CircuitDev& c, const BatchDev& bd, u32 B, u8* out_dev, hipStream_t s, int slot,
-                           hipEvent_t stagger);
+                           hipEvent_t stagger, hipEvent_t out_guard);
 
 // in_dev: B * (7*32 + N*32 + 8) ; ent_dev: B * (32 m + 32) ; out_dev: B * (1121 + 32 m).  All device pointers.
 int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* ent_dev, u8* out_dev, hipStream_t s) {
@@ -1047,6 +1047,7 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
     const size_t n_draws = 3 + 2 * (size_t)n1;
     if ((rc = dev_reserve(ctx, ctx->raw, (size_t)B * n_draws * 64))) return rc;
     hipStream_t main_s = s;
+    BBP_HIP_TRY(ctx, hipEventRecord(ctx->ev_entry[par], main_s));
     {
         hipStream_t s = ctx->side;  // opening stage
         // NOTE the opening stage does NOT wait for the caller's stream: in_dev / ent_dev must be complete when the call is
@@ -1067,7 +1068,7 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
         ctx->ev_open_valid[par] = true;
     }
     // HEAVY stage.  The batch is cut into slices (default 3, BBP_SLICES) that run the same kernel sequence on separate
-    // streams (slice 0 on the caller's): while one slice sits in a latency-bound step (the per-round transcript + scalar
+    // streams (slice 0 on the caller's -- a fifth concurrently active queue was measured 7 % slower): while one slice sits in a latency-bound step (the per-round transcript + scalar
     // inversion in k_ipa_round, the small encode / commit kernels) the other half's MSM keeps the CUs busy.
     const u32 slices = B >= 64u * (u32)ctx->slices ? (u32)ctx->slices : (B >= 128 ? 2u : 1u);
     const size_t rec = BBP_R1CS_PROOF_BYTES + 32 * (size_t)m;
@@ -1079,7 +1080,7 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
         // slice waits for the previous slice's first MSM, which puts its serial steps under the neighbour's MSMs
         if (i && ctx->stagger_mode) BBP_HIP_TRY(ctx, hipStreamWaitEvent(ls, ctx->ev_stagger[i - 1], 0));
         if ((rc = prove_heavy(ctx, c, batch_view(bd, c, first), last - first, out_dev + rec * first, ls, (int)i,
-                              i + 1 < slices ? ctx->ev_stagger[i] : nullptr)))
+                              i + 1 < slices ? ctx->ev_stagger[i] : nullptr, i ? ctx->ev_entry[par] : nullptr)))
             return rc;
         if (i) {
             BBP_HIP_TRY(ctx, hipEventRecord(ctx->ev_join[i], ls));
@@ -1106,7 +1107,7 @@ static BatchDev batch_view(const BatchDev& bd, const CircuitDev& c, u32 first) {
 
 // everything after the opening stage for `B` proofs of the view `bd`, on stream `s`, with MSM scratch slot `slot`
 static int32_t prove_heavy(bbp_ctx* ctx, const CircuitDev& c, const BatchDev& bd, u32 B, u8* out_dev, hipStream_t s, int slot,
-                           hipEvent_t stagger) {
+                           hipEvent_t stagger, hipEvent_t out_guard) {
     int32_t rc;
     const u32 m = c.m, n1 = c.n_mul, encw = (m + 8 + 22) * 8;
     DevBuf& ptsbuf = slot ? ctx->slice_pts[slot] : ctx->pts;
@@ -1163,6 +1164,9 @@ static int32_t prove_heavy(bbp_ctx* ctx, const CircuitDev& c, const BatchDev& bd
         }
     }
     LAUNCH(ctx, TAG_TRANSCRIPT, k_ipa_final, cdiv(B, 64), 64, s, B, m, bd.enc, bd.tr, bd.misc, bd.a, bd.b);
+    // a slice on an internal stream runs ahead of the caller's: its records must not land in out_dev before the work that was
+    // enqueued on the caller's stream ahead of this call (a consumer of the previous call's records, say) has finished
+    if (out_guard) BBP_HIP_TRY(ctx, hipStreamWaitEvent(s, out_guard, 0));
     LAUNCH(ctx, TAG_TRANSCRIPT, k_assemble, cdiv(B, 64), 64, s, B, m, bd.enc, bd.misc, out_dev);
     return BBP_OK;
 }

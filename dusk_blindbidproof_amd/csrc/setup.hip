@@ -113,6 +113,7 @@ extern "C" int32_t bbp_init(int32_t device, bbp_ctx** out) {
         BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_stagger[i - 1], hipEventDisableTiming));
     }
     BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_last, hipEventDisableTiming));
+    for (int i = 0; i < 2; i++) BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_entry[i], hipEventDisableTiming));
     if (const char* e = getenv("BBP_TAIL_ROUND")) ctx->tail_round = atoi(e) == bbp::FOLD_ROUND ? bbp::FOLD_ROUND : 12;
     if (const char* e = getenv("BBP_STAGGER")) ctx->stagger_mode = atoi(e);
     if (const char* e = getenv("BBP_SERIAL_BLOCK")) ctx->serial_block = atoi(e) == 64 ? 64 : atoi(e) == 128 ? 128 : 256;
@@ -189,6 +190,8 @@ extern "C" void bbp_free(bbp_ctx* ctx) {
         if (ctx->lane[i]) (void)hipStreamDestroy(ctx->lane[i]);
     }
     if (ctx->ev_last) (void)hipEventDestroy(ctx->ev_last);
+    for (int i = 0; i < 2; i++)
+        if (ctx->ev_entry[i]) (void)hipEventDestroy(ctx->ev_entry[i]);
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -102,7 +102,8 @@ int32_t bbp_verify_batch(bbp_ctx* ctx, uint32_t B, uint32_t N, const uint8_t* in
  * `stream` a hipStream_t (0 = context stream), no host synchronisation, no host-side argument screening
  * (toggle < N and canonical inputs are the caller's responsibility).  in_dev / entropy_dev must be COMPLETE when the call
  * is made: the prover's opening stage (witness, commitments, transcript rng) starts at once on an internal stream so that
- * it overlaps the previous call's MSM stage; outputs are ordered on `stream` as usual.  entropy_dev: B * bbp_entropy_size(N) for prove,
+ * it overlaps the previous call's MSM stage; outputs are ordered on `stream` as usual: complete for anything enqueued on
+ * `stream` after the call, and not written before everything enqueued on `stream` ahead of the call has finished.  entropy_dev: B * bbp_entropy_size(N) for prove,
  * B * 32 for verify (the verifier's TranscriptRng seed).  status_dev: B * int32. */
 int32_t bbp_prove_batch_dev(bbp_ctx* ctx, uint32_t B, uint32_t N, const void* in_dev, const void* entropy_dev, void* out_dev,
                             void* stream);
