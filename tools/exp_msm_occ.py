@@ -15,4 +15,4 @@ for B in (64, 256, 512, 1024, 2048, 4096):
     for _ in range(3): ctx.msm_batch_dev(B, n, sc.data_ptr(), 0, out.data_ptr(), s)
     t = [us for tag, us in ctx.last_timings() if tag == 1]
     ctx.set_profiling(False)
-    print("B=%5d  %.2f ms   -> %.3e madds/s" % (B, min(t) / 1e3, B * n * 23.0 / (min(t) * 1e-6)))
+    print("B=%5d  %.2f ms   -> %.3e madds/s" % (B, min(t) / 1e3, B * n * 19.85 / (min(t) * 1e-6)))
