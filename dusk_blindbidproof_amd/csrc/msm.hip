@@ -74,36 +74,41 @@ __device__ __forceinline__ ge xch_get(const u32* xch) {
     return p;
 }
 
-// one 128-byte row, one cache line.  The index is clamped: a corrupted scratch entry must never turn into an out-of-bounds
-// gather (a GPU fault here takes the whole node down); one v_min_u32 per ~1400-instruction iteration.
-__device__ __forceinline__ niels_row load_row(const niels_row* __restrict__ tab, u32 entry) {
+// one 128-byte row (one cache line) as the three field elements of a cached point, y+x and y-x already swapped for a negative
+// digit (the swap is two load offsets, not twenty selects).  The index is clamped: a corrupted scratch entry must never turn
+// into an out-of-bounds gather (a GPU fault here takes the whole node down); one v_min_u32 per ~1400-instruction iteration.
+struct row_regs {
+    fe ypx, ymx, xy2d;
+};
+
+__device__ __forceinline__ fe load_fe40(const u8* p) {  // 10 limbs at a 16-byte aligned address
+    const uint4 a = *reinterpret_cast<const uint4*>(p), b = *reinterpret_cast<const uint4*>(p + 16);
+    const uint2 c = *reinterpret_cast<const uint2*>(p + 32);
+    return fe{{(i32)a.x, (i32)a.y, (i32)a.z, (i32)a.w, (i32)b.x, (i32)b.y, (i32)b.z, (i32)b.w, (i32)c.x, (i32)c.y}};
+}
+
+__device__ __forceinline__ row_regs load_row(const niels_row* __restrict__ tab, u32 entry) {
     u32 row = min(entry & 0x7fffffffu, (u32)(TAB_BASES * MSM_POS - 1));
 #ifdef BBP_EXP_ROWMASK  // experiment (wrong results): alias all gathers onto a cache-resident slice of the table
     row &= BBP_EXP_ROWMASK;
 #endif
-    const uint4* p = reinterpret_cast<const uint4*>(tab + row);
-    uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4], q5 = p[5], q6 = p[6];
-    uint2 q7 = *reinterpret_cast<const uint2*>(p + 7);  // the two pad words are never loaded: they would cost two VGPRs
-    niels_row r;
-    const u32 w[30] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w,
-                       q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, q6.x, q6.y, q6.z, q6.w, q7.x, q7.y};
-#pragma unroll
-    for (int i = 0; i < 30; i++) r.v[i] = (i32)w[i];
+    const u8* p = reinterpret_cast<const u8*>(tab + row);
+    const u32 swap = (entry >> 31) << 6;  // 64 for a negative digit
+    row_regs r;
+    r.ypx = load_fe40(p + swap);
+    r.ymx = load_fe40(p + (swap ^ 64u));
+    const uint2 x0 = *reinterpret_cast<const uint2*>(p + 40);
+    const uint4 x1 = *reinterpret_cast<const uint4*>(p + 48);
+    const uint2 x2 = *reinterpret_cast<const uint2*>(p + 104), x3 = *reinterpret_cast<const uint2*>(p + 112);
+    r.xy2d = fe{{(i32)x0.x, (i32)x0.y, (i32)x1.x, (i32)x1.y, (i32)x1.z, (i32)x1.w, (i32)x2.x, (i32)x2.y, (i32)x3.x, (i32)x3.y}};
     return r;
 }
 
-// acc +/- row: mixed addition (7M); the sign swaps the roles of y+x / y-x and of D - C / D + C
-__device__ __forceinline__ ge ge_madd_row(const ge& p, const niels_row& q, bool neg) {
-    fe ypx, ymx, xy2d;
-#pragma unroll
-    for (int i = 0; i < 10; i++) {
-        ypx.v[i] = neg ? q.v[10 + i] : q.v[i];
-        ymx.v[i] = neg ? q.v[i] : q.v[10 + i];
-        xy2d.v[i] = q.v[20 + i];
-    }
-    fe a = fe_mul(fe_sub(p.Y, p.X), ymx);
-    fe b = fe_mul(fe_add(p.Y, p.X), ypx);
-    fe c = fe_mul(p.T, xy2d);
+// acc +/- row: mixed addition (7M); for a negative digit y+x / y-x arrive swapped and D - C / D + C swap roles
+__device__ __forceinline__ ge ge_madd_row(const ge& p, const row_regs& q, bool neg) {
+    fe a = fe_mul(fe_sub(p.Y, p.X), q.ymx);
+    fe b = fe_mul(fe_add(p.Y, p.X), q.ypx);
+    fe c = fe_mul(p.T, q.xy2d);
     fe d = fe_add(p.Z, p.Z);
     fe e = fe_sub(b, a), h = fe_add(b, a);
     fe f0 = fe_sub(d, c), g0 = fe_add(d, c);
@@ -279,7 +284,7 @@ void k_msm_acc(const niels_row* __restrict__ ptable, const u32* __restrict__ sor
         // iteration ahead, so neither load is waited for before a full mixed addition (~1300 instructions) has run
         u32 ent_cur = sorted[c0];
         u32 ent_nxt = (c0 + 1 < c1) ? sorted[c0 + 1] : 0u;
-        niels_row row = load_row(ptable, ent_cur);
+        row_regs row = load_row(ptable, ent_cur);
         for (u32 e = c0; e < c1; e++) {
             if (e == kend) {  // crossed into the next non-empty bucket
                 *dest = acc;
@@ -287,7 +292,7 @@ void k_msm_acc(const niels_row* __restrict__ ptable, const u32* __restrict__ sor
                 do { k++; kend = cursor[k]; } while (kend == e);
                 dest = &bsum[k - 1];
             }
-            const niels_row cur = row;
+            const row_regs cur = row;
             const bool neg = ent_cur >> 31;
             ent_cur = ent_nxt;
             if (e + 1 < c1) row = load_row(ptable, ent_cur);

@@ -21,7 +21,9 @@ struct niels_packed {  // the same three field elements as canonical 8-word valu
     u32 w[24];
 };
 
-struct alignas(128) niels_row {  // MSM table row: ypx[10] | ymx[10] | xy2d[10] | pad[2] as canonical limbs, one cache line
+// MSM table row, one cache line of canonical limbs: y+x at words 0..9, y-x at words 16..25 (byte offsets 0 and 64: a negative digit
+// swaps them by swapping two load offsets), 2dxy in the gaps (words 10..15 and 26..29), 2 pad words
+struct alignas(128) niels_row {
     i32 v[32];
 };
 
@@ -37,10 +39,15 @@ BBP_HD niels_row niels_to_row(const ge_niels& n) {
     niels_row r;
     u32 w[8];
     const fe* src[3] = {&n.ypx, &n.ymx, &n.xy2d};
+    fe c[3];
     for (int k = 0; k < 3; k++) {  // through the canonical words: limbs come out non-negative and fully carried
         fe_towords(w, *src[k]);
-        fe c = fe_fromwords(w);
-        for (int i = 0; i < 10; i++) r.v[10 * k + i] = c.v[i];
+        c[k] = fe_fromwords(w);
+    }
+    for (int i = 0; i < 10; i++) {
+        r.v[i] = c[0].v[i];
+        r.v[16 + i] = c[1].v[i];
+        r.v[i < 6 ? 10 + i : 20 + i] = c[2].v[i];  // 10..15, then 26..29
     }
     r.v[30] = r.v[31] = 0;
     return r;
