@@ -747,51 +747,70 @@ __global__ void k_tail_init(u32 B, sc* __restrict__ g_all, sc* __restrict__ h_al
 // L and R of a tail round (half length n <= 16) over the 32 + 32 materialised generators: one lane per (side, term), 33 terms a side.
 //   L = sum_{hi k} a[io] gg[k] F_G[k] + sum_{lo k} b[n+io] hh[k] F_H[k] + c_L w B      (k = blk 2n + {0, n} + io, rank = blk n + io)
 //   R = sum_{lo k} a[n+io] gg[k] F_G[k] + sum_{hi k} b[io] hh[k] F_H[k] + c_R w B
-// With `prev_round` != 0 the block first finishes the previous round: lane 0 absorbs L, R of that round, draws u and inverts it
-// (the other lanes wait), then the block folds a, b to length 2n and updates gg, hh in parallel.
-constexpr int TAIL_BLK = 128;
-__global__ __launch_bounds__(TAIL_BLK) void k_tail_lr(u32 n, u32 prev_round, u32 m, const u32* __restrict__ enc, merlin_transcript* __restrict__ tr,
+// With `prev_round` != 0 the block first finishes the previous round: the first lane of each proof absorbs L, R of that round,
+// draws u and inverts it (the other lanes wait), then the proof's lanes fold a, b to length 2n and update gg, hh in parallel.
+// Three proofs share a 256-lane block (66 lanes each: 33 terms a side), 77 % of the lanes doing scalar multiplications instead of
+// the 52 % of one proof per 128 lanes.
+constexpr int TAIL_BLK = 256, TAIL_PPB = 3, TAIL_LP = 66;
+__global__ __launch_bounds__(TAIL_BLK) void k_tail_lr(u32 B, u32 n, u32 prev_round, u32 m, const u32* __restrict__ enc, merlin_transcript* __restrict__ tr,
                                                        const sc* __restrict__ misc, sc* __restrict__ a_all, sc* __restrict__ b_all,
                                                        sc* __restrict__ g_all, sc* __restrict__ h_all, const ge* __restrict__ ftab,
                                                        const ge* __restrict__ btab, ge* __restrict__ lrpts) {
     BBP_THIN_PRIO();
     __shared__ u32 stage[GE_WORDS * TAIL_BLK];
-    const u32 p = blockIdx.x, tid = threadIdx.x;
-    const u32 side = tid >> 6, j = tid & 63;  // 64 slots per side, 33 used
-    sc *a = a_all + (size_t)p * 2048, *b = b_all + (size_t)p * 2048, *gg = g_all + (size_t)p * 2048, *hh = h_all + (size_t)p * 2048;
+    __shared__ u32 uu_w[TAIL_PPB * 2 * 8];
+    const u32 tid = threadIdx.x;
+    const u32 pj = tid / TAIL_LP, l = tid % TAIL_LP;        // proof slot in the block, lane within the proof
+    const u32 p = blockIdx.x * TAIL_PPB + pj;
+    const bool live = pj < TAIL_PPB && p < B;
+    const u32 side = l / 33, j = l % 33;                    // j: 0..15 G terms, 16..31 H terms, 32 the B term
+    const size_t po = live ? (size_t)p : 0;
+    sc *a = a_all + po * 2048, *b = b_all + po * 2048, *gg = g_all + po * 2048, *hh = h_all + po * 2048;
     if (prev_round) {
-        sc* uu = reinterpret_cast<sc*>(stage);  // u, 1/u
-        if (tid == 0) {
+        if (live && l == 0) {
             merlin_transcript t = tr[p];
             const u32* e = enc + (size_t)p * enc_stride_words(m) + 8 * (m + 8) + 16 * (prev_round - 1);
             tr_append_words(t, LBL("L"), e);
             tr_append_words(t, LBL("R"), e + 8);
-            const sc u = tr_challenge_sc(t, LBL("u"));
-            uu[0] = u;
-            uu[1] = sc_invert(u);
+            const sc u = tr_challenge_sc(t, LBL("u")), ui = sc_invert(u);
+#pragma unroll
+            for (int w = 0; w < 8; w++) {
+                uu_w[(pj * 2) * 8 + w] = u.v[w];
+                uu_w[(pj * 2 + 1) * 8 + w] = ui.v[w];
+            }
             tr[p] = t;
         }
         __syncthreads();
-        const sc u = uu[0], ui = uu[1];
-        const u32 n2 = 2 * n;
-        if (tid < n2) {
-            st_sc(&a[tid], sc_add(sc_mul(ld_sc(&a[tid]), u), sc_mul(ui, ld_sc(&a[n2 + tid]))));
-        } else if (tid < 2 * n2) {
-            const u32 i = tid - n2;
-            st_sc(&b[i], sc_add(sc_mul(ld_sc(&b[i]), ui), sc_mul(u, ld_sc(&b[n2 + i]))));
-        } else if (tid >= 64) {
-            const u32 k = tid & 31;
-            const bool hi = (k & (2 * n2 - 1)) >= n2;
-            if (tid < 96) st_sc(&gg[k], sc_mul(ld_sc(&gg[k]), hi ? u : ui));
-            else st_sc(&hh[k], sc_mul(ld_sc(&hh[k]), hi ? ui : u));
+        if (live) {
+            sc u, ui;
+#pragma unroll
+            for (int w = 0; w < 8; w++) {
+                u.v[w] = uu_w[(pj * 2) * 8 + w];
+                ui.v[w] = uu_w[(pj * 2 + 1) * 8 + w];
+            }
+            const u32 n2 = 2 * n;
+            // work items of one proof: n2 folds of a, n2 folds of b, 32 factors gg, 32 factors hh
+            for (u32 w = l; w < 2 * n2 + 2 * FOLD_CLS; w += TAIL_LP) {
+                if (w < n2) {
+                    st_sc(&a[w], sc_add(sc_mul(ld_sc(&a[w]), u), sc_mul(ui, ld_sc(&a[n2 + w]))));
+                } else if (w < 2 * n2) {
+                    const u32 i = w - n2;
+                    st_sc(&b[i], sc_add(sc_mul(ld_sc(&b[i]), ui), sc_mul(u, ld_sc(&b[n2 + i]))));
+                } else {
+                    const u32 k = (w - 2 * n2) % FOLD_CLS;
+                    const bool hi = (k & (2 * n2 - 1)) >= n2;
+                    if (w - 2 * n2 < FOLD_CLS) st_sc(&gg[k], sc_mul(ld_sc(&gg[k]), hi ? u : ui));
+                    else st_sc(&hh[k], sc_mul(ld_sc(&hh[k]), hi ? ui : u));
+                }
+            }
         }
         __threadfence_block();
         __syncthreads();
     }
-    const ge *FG = ftab + (size_t)p * 2 * FOLD_CLS * TAIL_TAB, *FH = FG + (size_t)FOLD_CLS * TAIL_TAB;  // tables of F_G[32], F_H[32]
+    const ge *FG = ftab + po * 2 * FOLD_CLS * TAIL_TAB, *FH = FG + (size_t)FOLD_CLS * TAIL_TAB;  // tables of F_G[32], F_H[32]
     constexpr u32 HALF = FOLD_CLS / 2;  // 16 G-terms and 16 H-terms per side
     ge q = ge_identity();
-    if (j <= 2 * HALF) {
+    if (live) {
         sc s;
         const ge* T;
         if (j < 2 * HALF) {
@@ -818,8 +837,9 @@ __global__ __launch_bounds__(TAIL_BLK) void k_tail_lr(u32 n, u32 prev_round, u32
     const u32* w = reinterpret_cast<const u32*>(&q);
     for (int k = 0; k < GE_WORDS; k++) stage[k * TAIL_BLK + tid] = w[k];
     __syncthreads();
+    // tree sum inside each group of 33 consecutive lanes (one group per proof and side)
     for (int d = 32; d >= 1; d >>= 1) {
-        if (j < (u32)d) {
+        if (live && j < (u32)d && j + d < 33) {
             ge o;
             u32* ow = reinterpret_cast<u32*>(&o);
             for (int k = 0; k < GE_WORDS; k++) ow[k] = stage[k * TAIL_BLK + tid + d];
@@ -828,7 +848,7 @@ __global__ __launch_bounds__(TAIL_BLK) void k_tail_lr(u32 n, u32 prev_round, u32
         }
         __syncthreads();
     }
-    if (j == 0) lrpts[(size_t)p * 2 + side] = q;
+    if (live && j == 0) lrpts[(size_t)p * 2 + side] = q;
 }
 
 __global__ BBP_LANE_KERNEL void k_ipa_final(u32 B, u32 m, const u32* __restrict__ enc, merlin_transcript* __restrict__ tr, sc* __restrict__ misc,
@@ -1158,7 +1178,7 @@ static int32_t prove_heavy(bbp_ctx* ctx, const CircuitDev& c, const BatchDev& bd
         LAUNCH(ctx, TAG_VARBASE, k_tail_tables, cdiv(B * 2 * FOLD_CLS, 64), 64, s, B * 2 * FOLD_CLS, bd.fpts, ftab);
         for (u32 r = tail_from; r <= 11; r++) {
             const u32 n = 1024u >> (r - 1);
-            LAUNCH(ctx, TAG_VARBASE, k_tail_lr, B, TAIL_BLK, s, n, r > tail_from ? r - 1 : 0u, m, bd.enc, bd.tr, bd.misc, bd.a, bd.b, bd.g, bd.h, ftab,
+            LAUNCH(ctx, TAG_VARBASE, k_tail_lr, cdiv(B, TAIL_PPB), TAIL_BLK, s, B, n, r > tail_from ? r - 1 : 0u, m, bd.enc, bd.tr, bd.misc, bd.a, bd.b, bd.g, bd.h, ftab,
                    ctx->btab, bd.lrpts);
             LAUNCH(ctx, TAG_ENCODE, k_encode_strided, cdiv(2 * B, 64), 64, s, 2 * B, 2u, bd.lrpts, 2u, bd.enc, encw, 8 * (m + 8 + 2 * (r - 1)));
         }
