@@ -751,7 +751,10 @@ __global__ void k_tail_init(u32 B, sc* __restrict__ g_all, sc* __restrict__ h_al
 // draws u and inverts it (the other lanes wait), then the proof's lanes fold a, b to length 2n and update gg, hh in parallel.
 // Three proofs share a 256-lane block (66 lanes each: 33 terms a side), 77 % of the lanes doing scalar multiplications instead of
 // the 52 % of one proof per 128 lanes.
-constexpr int TAIL_BLK = 256, TAIL_PPB = 3, TAIL_LP = 66;
+#ifndef BBP_TAIL_BLK
+#define BBP_TAIL_BLK 256
+#endif
+constexpr int TAIL_BLK = BBP_TAIL_BLK, TAIL_LP = 66, TAIL_PPB = TAIL_BLK / TAIL_LP;
 __global__ __launch_bounds__(TAIL_BLK) void k_tail_lr(u32 B, u32 n, u32 prev_round, u32 m, const u32* __restrict__ enc, merlin_transcript* __restrict__ tr,
                                                        const sc* __restrict__ misc, sc* __restrict__ a_all, sc* __restrict__ b_all,
                                                        sc* __restrict__ g_all, sc* __restrict__ h_all, const ge* __restrict__ ftab,
