@@ -81,7 +81,7 @@ NAF12_DIGITS, NAF9_DIGITS = 19.85, 25.66
 # HBM bytes per accumulate-kernel launch (k_msm_acc, a third of the batch per launch) from the rocprofv3 PMC passes on B = 1024,
 # N = 8 (profiles/r01_rocprofv3_pmc_hbm.csv, weighted over the <0> and <1> instances): FETCH_SIZE x 2 (gfx950 reports half of
 # wide reads, MI355X_MICROARCH.md HBM section) + WRITE_SIZE
-MEASURED_TRAFFIC_PROVE_1024_8 = (2 * 1715242 + 506779) * 1024
+MEASURED_TRAFFIC_PROVE_1024_8 = (2 * 1714396 + 508698) * 1024
 
 
 class _Base:
