@@ -52,6 +52,8 @@ struct bbp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;            // opening stage of the prover pipeline (prover.hip)
+    hipStream_t side2 = nullptr;           // second opening stream: batches too small to fill three heavy slices alternate between the two
+    int dual_open_below = 1024;            // batches smaller than this open on alternating streams (BBP_DUAL_OPEN_BELOW, 0 = never)
     static constexpr int MAX_SLICES = 4;   // heavy-stage slices of one batch, one stream each (slice 0 = caller's stream)
     hipStream_t lane[MAX_SLICES] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_join[MAX_SLICES] = {nullptr, nullptr, nullptr, nullptr}, ev_stagger[MAX_SLICES] = {nullptr, nullptr, nullptr, nullptr};
@@ -61,9 +63,10 @@ struct bbp_ctx {
     int serial_block = 64;        // threads per workgroup of those kernels: 256 = one serial wave per SIMD of the reserved CU (BBP_SERIAL_BLOCK)
     std::map<const void*, int> serial_attr;
     int stagger_mode = 0;  // 0: slices start together, 1: next slice starts after this slice's first MSM, 3: after its third (BBP_STAGGER)
-    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_open[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
-    hipEvent_t ev_entry[2] = {nullptr, nullptr};  // caller's stream at entry of a prove call: out_dev is not written before it
-    bool ev_done_valid[2] = {false, false}, ev_open_valid[2] = {false, false};
+    static constexpr int PROVE_BUFS = 3;  // prover batch buffers in rotation (call k uses buffer k % 3)
+    hipEvent_t ev_open[PROVE_BUFS] = {nullptr, nullptr, nullptr}, ev_done[PROVE_BUFS] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_entry[PROVE_BUFS] = {nullptr, nullptr, nullptr};  // caller's stream at entry of a prove call: out_dev is not written before it
+    bool ev_done_valid[PROVE_BUFS] = {false, false, false}, ev_open_valid[PROVE_BUFS] = {false, false, false};
     uint32_t seq = 0;
     int last_par = 0;
     // calls on one context share scratch buffers: a call issued on a different caller stream than the previous one is ordered
@@ -81,7 +84,7 @@ struct bbp_ctx {
     uint8_t gens_enc_host_valid = 0;
     std::vector<uint8_t> mimc_host;    // 90 * 32
     // grow-only scratch
-    bbp::DevBuf scal, idx, sorted, pts, enc, misc, batch, batch1, batch2, io_in, io_out, io_ent, raw;
+    bbp::DevBuf scal, idx, sorted, pts, enc, misc, batch[PROVE_BUFS + 1], io_in, io_out, io_ent, raw[2];  // batch[3]: the verifier's; raw[i]: draw buffer of opening stream i
     bbp::DevBuf slice_sorted[MAX_SLICES], slice_pts[MAX_SLICES], slice_fold[MAX_SLICES], slice_vtab[MAX_SLICES];  // per-slice MSM scratch (slice 0 uses sorted / pts)
     std::map<uint32_t, void*> circuits;  // N -> CircuitDev* (compiled blind-bid circuit tables on the device)
     std::vector<float> timings;

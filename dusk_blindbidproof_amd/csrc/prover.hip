@@ -970,7 +970,7 @@ int32_t circuit_get(bbp_ctx* ctx, uint32_t n_items, const CircuitDev** out) {
 
 int32_t batch_reserve(bbp_ctx* ctx, uint32_t B, const CircuitDev& c, BatchDev& bd, int parity) {
     const size_t n1 = c.n_mul, m = c.m;
-    DevBuf& buf = parity == 2 ? ctx->batch2 : parity ? ctx->batch1 : ctx->batch;  // 0 / 1: the prover's call parities, 2: the verifier
+    DevBuf& buf = ctx->batch[parity];  // 0..2: the prover's buffers in rotation, 3 (VERIFY_BUF): the verifier's
     size_t off = 0;
     auto take = [&](size_t bytes_per_proof) {
         size_t o = off;
@@ -1062,17 +1062,24 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
     // still busy with the MSM-heavy stage of the PREVIOUS call (other parity).  Events order: inputs (caller stream) ->
     // opening (side) -> heavy stage (caller stream); a buffer is reused only after its previous heavy stage has finished.
     if ((rc = stream_guard_enter(ctx, s))) return rc;
-    const int par = (int)(ctx->seq++ & 1u);
+    const u32 call = ctx->seq++;
+    // Batches too small to fill three heavy slices are bound by the opening stage (its rng chain lasts ~40 ms whatever the
+    // batch size), so their openings alternate between two streams and two of them are in flight at once; the heavy stage
+    // is then cut in at most two slices so that no more than four queues are active (a fifth costs ~7 %).
+    const bool dual = B < (u32)(ctx->dual_open_below > 0 ? ctx->dual_open_below : 0);
+    const int sidx = dual ? (int)(call & 1u) : 0;
+    const int par = dual ? (int)(call % (u32)bbp_ctx::PROVE_BUFS) : (int)(call & 1u);  // two openings in flight need a third buffer
+    if (dual && !ctx->side2) BBP_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side2, hipStreamNonBlocking));
     BatchDev bd;
     if ((rc = batch_reserve(ctx, B, c, bd, par))) return rc;
     const u32 m = c.m, n1 = c.n_mul, encw = (m + 8 + 22) * 8;
     const merlin_transcript prefix = prover_prefix();
     const size_t n_draws = 3 + 2 * (size_t)n1;
-    if ((rc = dev_reserve(ctx, ctx->raw, (size_t)B * n_draws * 64))) return rc;
+    if ((rc = dev_reserve(ctx, ctx->raw[sidx], (size_t)B * n_draws * 64))) return rc;
     hipStream_t main_s = s;
     BBP_HIP_TRY(ctx, hipEventRecord(ctx->ev_entry[par], main_s));
     {
-        hipStream_t s = ctx->side;  // opening stage
+        hipStream_t s = sidx ? ctx->side2 : ctx->side;  // opening stage
         // NOTE the opening stage does NOT wait for the caller's stream: in_dev / ent_dev must be complete when the call is
         // made (include/bbp.h).  Waiting on the caller's stream tail would serialise it behind the previous call's heavy stage.
         if (ctx->ev_done_valid[par]) BBP_HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_done[par], 0));
@@ -1085,15 +1092,16 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
         if ((rc = commit_launch(ctx, B * m, bd.v, bd.vb, m, m, m, bd.pts, m + 8, s))) return rc;
         LAUNCH(ctx, TAG_ENCODE, k_encode_strided, cdiv(B * m, 64), 64, s, B * m, m, bd.pts, m + 8, bd.enc, encw, 0u);
         LAUNCH_LDS(ctx, TAG_RNG, k_open_serial, 2 * cdiv(B, sblk), sblk, hog, s, B, cdiv(B, sblk), m, n1, prefix, bd.enc, ent_dev, bd.vb,
-                   (u32*)ctx->raw.p, bd.tr, bd.rng, c.n_cst, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v, bd.ai1, bd.ao1);
-        LAUNCH(ctx, TAG_RNG, k_reduce_draws, cdiv((u32)(B * n_draws), 128), 128, s, B, n1, (const u32*)ctx->raw.p, bd.ai1, bd.ao1, bd.s1);
+                   (u32*)ctx->raw[sidx].p, bd.tr, bd.rng, c.n_cst, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v, bd.ai1, bd.ao1);
+        LAUNCH(ctx, TAG_RNG, k_reduce_draws, cdiv((u32)(B * n_draws), 128), 128, s, B, n1, (const u32*)ctx->raw[sidx].p, bd.ai1, bd.ao1, bd.s1);
         BBP_HIP_TRY(ctx, hipEventRecord(ctx->ev_open[par], s));
         ctx->ev_open_valid[par] = true;
     }
     // HEAVY stage.  The batch is cut into slices (default 3, BBP_SLICES) that run the same kernel sequence on separate
     // streams (slice 0 on the caller's -- a fifth concurrently active queue was measured 7 % slower): while one slice sits in a latency-bound step (the per-round transcript + scalar
     // inversion in k_ipa_round, the small encode / commit kernels) the other half's MSM keeps the CUs busy.
-    const u32 slices = B >= 64u * (u32)ctx->slices ? (u32)ctx->slices : (B >= 128 ? 2u : 1u);
+    u32 slices = B >= 64u * (u32)ctx->slices ? (u32)ctx->slices : (B >= 128 ? 2u : 1u);
+    if (dual && slices > 2) slices = 2;
     const size_t rec = BBP_R1CS_PROOF_BYTES + 32 * (size_t)m;
     for (u32 i = 0; i < slices; i++) {
         const u32 first = (u32)(((u64)B * i) / slices), last = (u32)(((u64)B * (i + 1)) / slices);

@@ -113,14 +113,14 @@ extern "C" int32_t bbp_init(int32_t device, bbp_ctx** out) {
         BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_stagger[i - 1], hipEventDisableTiming));
     }
     BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_last, hipEventDisableTiming));
-    for (int i = 0; i < 2; i++) BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_entry[i], hipEventDisableTiming));
+    if (const char* e = getenv("BBP_DUAL_OPEN_BELOW")) ctx->dual_open_below = atoi(e);
     if (const char* e = getenv("BBP_TAIL_ROUND")) ctx->tail_round = atoi(e) == bbp::FOLD_ROUND ? bbp::FOLD_ROUND : 12;
     if (const char* e = getenv("BBP_STAGGER")) ctx->stagger_mode = atoi(e);
     if (const char* e = getenv("BBP_SERIAL_BLOCK")) ctx->serial_block = atoi(e) == 64 ? 64 : atoi(e) == 128 ? 128 : 256;
     if (const char* e = getenv("BBP_SERIAL_LDS")) ctx->serial_lds = atoi(e) < 0 ? 0 : atoi(e) > 160 * 1024 ? 160 * 1024 : atoi(e);
     if (const char* e = getenv("BBP_SLICES")) ctx->slices = atoi(e) < 1 ? 1 : atoi(e) > bbp_ctx::MAX_SLICES ? bbp_ctx::MAX_SLICES : atoi(e);
-    for (int i = 0; i < 2; i++) {
-        BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_in[i], hipEventDisableTiming));
+    for (int i = 0; i < bbp_ctx::PROVE_BUFS; i++) {
+        BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_entry[i], hipEventDisableTiming));
         BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_open[i], hipEventDisableTiming));
         BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_done[i], hipEventDisableTiming));
     }
@@ -167,7 +167,7 @@ extern "C" void bbp_free(bbp_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     void* ptrs[] = {ctx->gens, ctx->ptable, ctx->btab, ctx->slice_fold[0].p, ctx->slice_fold[1].p, ctx->slice_fold[2].p, ctx->slice_fold[3].p,
-                    ctx->slice_vtab[0].p, ctx->slice_vtab[1].p, ctx->slice_vtab[2].p, ctx->slice_vtab[3].p, ctx->comb, ctx->mimc_c, ctx->scal.p, ctx->idx.p, ctx->sorted.p, ctx->pts.p, ctx->enc.p, ctx->misc.p, ctx->batch.p, ctx->io_in.p, ctx->io_out.p, ctx->io_ent.p, ctx->raw.p, ctx->batch1.p, ctx->batch2.p, ctx->slice_sorted[1].p, ctx->slice_sorted[2].p, ctx->slice_sorted[3].p, ctx->slice_pts[1].p, ctx->slice_pts[2].p, ctx->slice_pts[3].p};
+                    ctx->slice_vtab[0].p, ctx->slice_vtab[1].p, ctx->slice_vtab[2].p, ctx->slice_vtab[3].p, ctx->comb, ctx->mimc_c, ctx->scal.p, ctx->idx.p, ctx->sorted.p, ctx->pts.p, ctx->enc.p, ctx->misc.p, ctx->batch[0].p, ctx->io_in.p, ctx->io_out.p, ctx->io_ent.p, ctx->raw[0].p, ctx->raw[1].p, ctx->batch[1].p, ctx->batch[2].p, ctx->batch[3].p, ctx->slice_sorted[1].p, ctx->slice_sorted[2].p, ctx->slice_sorted[3].p, ctx->slice_pts[1].p, ctx->slice_pts[2].p, ctx->slice_pts[3].p};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& kv : ctx->circuits) {  // compiled circuits (one per list length used)
@@ -179,8 +179,8 @@ extern "C" void bbp_free(bbp_ctx* ctx) {
         delete c;
     }
     ctx->circuits.clear();
-    for (int i = 0; i < 2; i++) {
-        if (ctx->ev_in[i]) (void)hipEventDestroy(ctx->ev_in[i]);
+    for (int i = 0; i < bbp_ctx::PROVE_BUFS; i++) {
+        if (ctx->ev_entry[i]) (void)hipEventDestroy(ctx->ev_entry[i]);
         if (ctx->ev_open[i]) (void)hipEventDestroy(ctx->ev_open[i]);
         if (ctx->ev_done[i]) (void)hipEventDestroy(ctx->ev_done[i]);
     }
@@ -190,9 +190,8 @@ extern "C" void bbp_free(bbp_ctx* ctx) {
         if (ctx->lane[i]) (void)hipStreamDestroy(ctx->lane[i]);
     }
     if (ctx->ev_last) (void)hipEventDestroy(ctx->ev_last);
-    for (int i = 0; i < 2; i++)
-        if (ctx->ev_entry[i]) (void)hipEventDestroy(ctx->ev_entry[i]);
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
+    if (ctx->side2) (void)hipStreamDestroy(ctx->side2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -301,6 +301,50 @@ def test_engine_schedules_give_identical_bytes(bbp, oc, knobs):
         c2.close()
 
 
+def test_pipelined_calls_of_mixed_batch_sizes(bbp, oc):
+    """Back-to-back device calls without host synchronisation, alternating between batch sizes below and above the
+    dual-opening threshold (two opening streams over three buffers vs one stream over two): every call must reproduce the
+    records of the same inputs proven alone, and the oracle's record for a sampled proof."""
+    import os
+    import torch
+    dev = torch.device("cuda", 0)
+    old = os.environ.get("BBP_DUAL_OPEN_BELOW")
+    os.environ["BBP_DUAL_OPEN_BELOW"] = "128"
+    try:
+        c2 = bbp.Context(0)
+    finally:
+        if old is None:
+            os.environ.pop("BBP_DUAL_OPEN_BELOW", None)
+        else:
+            os.environ["BBP_DUAL_OPEN_BELOW"] = old
+    try:
+        N = 2
+        rs_ = bbp.record_size(N)
+        sets = []
+        for k, B in enumerate((70, 130, 96, 192, 33)):  # 70 / 96 / 33 open on alternating streams, 130 / 192 on the single one
+            ins, ents, _ = _synth_batch(c2, B, N, seed=900 + k)
+            d_in = torch.frombuffer(bytearray(b"".join(ins)), dtype=torch.uint8).to(dev)
+            d_ent = torch.frombuffer(bytearray(b"".join(ents)), dtype=torch.uint8).to(dev)
+            solo, st = c2.prove_batch(B, N, b"".join(ins), b"".join(ents))
+            assert st == [0] * B
+            rc, exp = oc.prove(ins[B - 1][:224], ins[B - 1][224:224 + 32 * N], int.from_bytes(ins[B - 1][-8:], "little"), ents[B - 1])
+            assert rc == 0 and solo[(B - 1) * rs_:] == exp
+            sets.append((B, d_in, d_ent, solo))
+        torch.cuda.synchronize()
+        s = torch.cuda.current_stream().cuda_stream
+        outs = []
+        for it in range(15):
+            B, d_in, d_ent, solo = sets[(it * 3) % 5]
+            out = torch.zeros(B * rs_, dtype=torch.uint8, device=dev)
+            c2.prove_batch_dev(B, N, d_in.data_ptr(), d_ent.data_ptr(), out.data_ptr(), s)
+            outs.append((out, solo))
+        torch.cuda.synchronize()
+        for it, (out, solo) in enumerate(outs):
+            assert bytes(out.cpu().numpy().tobytes()) == solo, it
+    finally:
+        c2.close()
+
+
 def test_config3_full_batch(ctx, oc, bbp):
     """SURVEY.md 8d config 3 at full size: 1024 full proves (N = 8) in one batch call; the first 16 and the last 4 records
     byte-compared with the C oracle under the same entropy, every proof accepted by the device verifier, a spread sample of 48
