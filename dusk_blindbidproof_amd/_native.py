@@ -35,6 +35,8 @@ SIGNATURES = {
     "bbp_verify_batch": (_i32, [_vp, _u32, _u32, _vp, _vp]),
     "bbp_prove_batch_dev": (_i32, [_vp, _u32, _u32, _vp, _vp, _vp, _vp]),
     "bbp_verify_batch_dev": (_i32, [_vp, _u32, _u32, _vp, _vp, _vp, _vp]),
+    "bbp_verify_batch_aggregated": (_i32, [_vp, _u32, _u32, _vp, _vp, _u32, _vp]),
+    "bbp_verify_batch_aggregated_dev": (_i32, [_vp, _u32, _u32, _vp, _vp, _vp, _u32, _vp, _vp]),
     "bbp_debug_challenges": (_i32, [_vp, _u32, _u32, _u32, _vp]),
     "bbp_ubench": (_i32, [_vp, _i32, _u32, _u32, ctypes.POINTER(ctypes.c_double)]),
     "bbp_set_profiling": (_i32, [_vp, _i32]),
@@ -158,6 +160,19 @@ class Context:
         status = (ctypes.c_int32 * B)()
         self._check(lib.bbp_verify_batch(self._h, B, N, _buf(inputs), status))
         return list(status)
+
+    def verify_batch_aggregated(self, B, N, inputs, group=0):
+        """Statuses as verify_batch; proofs are checked in groups of `group` (0 = default 32) with one generator MSM per group,
+        failing groups proof by proof.  Returns (statuses, number of proofs that took the per-proof path)."""
+        status = (ctypes.c_int32 * B)()
+        nfb = ctypes.c_uint32()
+        self._check(lib.bbp_verify_batch_aggregated(self._h, B, N, _buf(inputs), status, group, ctypes.byref(nfb)))
+        return list(status), nfb.value
+
+    def verify_batch_aggregated_dev(self, B, N, in_ptr, ent_ptr, status_ptr, group=0, stream=0):
+        nfb = ctypes.c_uint32()
+        self._check(lib.bbp_verify_batch_aggregated_dev(self._h, B, N, in_ptr, ent_ptr, status_ptr, group, ctypes.byref(nfb), stream))
+        return nfb.value
 
     def prove_batch_dev(self, B, N, in_ptr, ent_ptr, out_ptr, stream=0):
         self._check(lib.bbp_prove_batch_dev(self._h, B, N, in_ptr, ent_ptr, out_ptr, stream))

@@ -9,7 +9,7 @@ namespace bbp {
 // slots of the per-proof `misc` scalar block
 enum MiscSlot : int {
     MS_Y = 0, MS_Z, MS_U, MS_X, MS_W, MS_YINV, MS_T1, MS_T2, MS_T3, MS_T4, MS_T5, MS_T6, MS_TB1, MS_TB2, MS_TB3, MS_TB4, MS_TB5,
-    MS_TB6, MS_TX, MS_TXB, MS_EBL, MS_UJ, MS_UJI, MS_A0, MS_B0, MS_R, MS_ALLINV, MS_WC, MS_DELTA, MS_COUNT = 32
+    MS_TB6, MS_TX, MS_TXB, MS_EBL, MS_UJ, MS_UJI, MS_A0, MS_B0, MS_R, MS_ALLINV, MS_WC, MS_DELTA, MS_RHO /* aggregated verification: the proof's random weight */, MS_COUNT = 32
 };
 
 struct CircuitDev {  // compiled circuit tables resident on the device (one per bid-list length N)

@@ -7,7 +7,9 @@
 namespace bbp {
 int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* ent_dev, u8* out_dev, hipStream_t s);
 int32_t verify_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* ent_dev, int32_t* status_dev, hipStream_t s);
-int32_t verify_batch_dev_ex(bbp_ctx* ctx, u32 B, u32 N, u32 rec_ver, const u8* in_dev, const u8* ent_dev, int32_t* status_dev, hipStream_t s);
+int32_t verify_batch_dev_ex(bbp_ctx* ctx, u32 B, u32 N, u32 rec_ver, u32 G, const u8* in_dev, const u8* ent_dev, int32_t* status_dev, hipStream_t s);
+int32_t verify_batch_agg_dev(bbp_ctx* ctx, u32 B, u32 N, u32 G, const u8* in_dev, const u8* ent_dev, int32_t* status_dev, hipStream_t s,
+                             u32* n_fallback);
 int32_t debug_read_misc(bbp_ctx* ctx, u32 B, u32 N, u32 proof, uint8_t* out);
 
 // native (non-circuit) image of the gadget wiring: what the reference's Go caller computes before Proof::prove
@@ -181,7 +183,8 @@ extern "C" int32_t bbp_prove(bbp_ctx* ctx, const uint8_t scalars7[7 * 32], const
 }
 
 // rec_ver 0: compact 1121-byte proofs; 1: the 2-phase 1217-byte R1CSProof layout (both parse in the reference)
-static int32_t verify_batch_host(bbp_ctx* ctx, uint32_t B, uint32_t N, uint32_t rec_ver, const uint8_t* in, int32_t* status) {
+static int32_t verify_batch_host(bbp_ctx* ctx, uint32_t B, uint32_t N, uint32_t rec_ver, const uint8_t* in, int32_t* status,
+                                 uint32_t group = 0, uint32_t* n_fallback = nullptr) {
     int32_t rc;
     BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t stride = (size_t)(rec_ver ? 1217u : 1121u) + 32 * (4 + (size_t)N) + 96 + (size_t)N * 32;
@@ -196,7 +199,12 @@ static int32_t verify_batch_host(bbp_ctx* ctx, uint32_t B, uint32_t N, uint32_t 
     BBP_HIP_TRY(ctx, hipMemcpyAsync(ctx->io_in.p, in, stride * B, hipMemcpyHostToDevice, ctx->stream));
     BBP_HIP_TRY(ctx, hipMemcpyAsync(ctx->io_ent.p, ent.data(), ent.size(), hipMemcpyHostToDevice, ctx->stream));
     BBP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if ((rc = verify_batch_dev_ex(ctx, B, N, rec_ver, (const u8*)ctx->io_in.p, (const u8*)ctx->io_ent.p, (int32_t*)ctx->io_out.p, ctx->stream)))
+    if (group > 1) {
+        if ((rc = verify_batch_agg_dev(ctx, B, N, group, (const u8*)ctx->io_in.p, (const u8*)ctx->io_ent.p, (int32_t*)ctx->io_out.p,
+                                       ctx->stream, n_fallback)))
+            return rc;
+    } else if ((rc = verify_batch_dev_ex(ctx, B, N, rec_ver, 0, (const u8*)ctx->io_in.p, (const u8*)ctx->io_ent.p, (int32_t*)ctx->io_out.p,
+                                         ctx->stream)))
         return rc;
     BBP_HIP_TRY(ctx, hipMemcpyAsync(status, ctx->io_out.p, 4 * (size_t)B, hipMemcpyDeviceToHost, ctx->stream));
     BBP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -220,6 +228,28 @@ extern "C" int32_t bbp_verify_batch_dev(bbp_ctx* ctx, uint32_t B, uint32_t N, co
     BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return verify_batch_dev(ctx, B, N, (const u8*)in_dev, (const u8*)entropy_dev, (int32_t*)status_dev,
                             stream ? (hipStream_t)stream : ctx->stream);
+}
+
+extern "C" int32_t bbp_verify_batch_aggregated(bbp_ctx* ctx, uint32_t B, uint32_t N, const uint8_t* in, int32_t* status, uint32_t group,
+                                               uint32_t* n_fallback) {
+    if (n_fallback) *n_fallback = 0;
+    if (!ctx || !in || !status) return BBP_ERR_BAD_ARG;
+    int32_t rc = check_n(ctx, N);
+    if (rc) return rc;
+    if (B == 0) return BBP_OK;
+    return verify_batch_host(ctx, B, N, 0, in, status, group ? group : BBP_AGG_GROUP_DEFAULT, n_fallback);
+}
+
+extern "C" int32_t bbp_verify_batch_aggregated_dev(bbp_ctx* ctx, uint32_t B, uint32_t N, const void* in_dev, const void* entropy_dev,
+                                                   void* status_dev, uint32_t group, uint32_t* n_fallback, void* stream) {
+    if (n_fallback) *n_fallback = 0;
+    if (!ctx || !in_dev || !entropy_dev || !status_dev) return BBP_ERR_BAD_ARG;
+    int32_t rc = check_n(ctx, N);
+    if (rc) return rc;
+    if (B == 0) return BBP_OK;
+    BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return verify_batch_agg_dev(ctx, B, N, group ? group : BBP_AGG_GROUP_DEFAULT, (const u8*)in_dev, (const u8*)entropy_dev,
+                                (int32_t*)status_dev, stream ? (hipStream_t)stream : ctx->stream, n_fallback);
 }
 
 extern "C" int32_t bbp_verify(bbp_ctx* ctx, const uint8_t* record, uint32_t record_len, const uint8_t score[32], const uint8_t z_img[32],

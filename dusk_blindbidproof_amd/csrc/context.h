@@ -53,6 +53,7 @@ struct bbp_ctx {
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;            // opening stage of the prover pipeline (prover.hip)
     hipStream_t side2 = nullptr;           // second opening stream: batches too small to fill three heavy slices alternate between the two
+    int varbase_lanes = 65536;             // lanes the verifier's variable-base kernel is launched with (BBP_VARBASE_LANES): ~1 wave per SIMD
     int dual_open_below = 1024;            // batches smaller than this open on alternating streams (BBP_DUAL_OPEN_BELOW, 0 = never)
     static constexpr int MAX_SLICES = 4;   // heavy-stage slices of one batch, one stream each (slice 0 = caller's stream)
     hipStream_t lane[MAX_SLICES] = {nullptr, nullptr, nullptr, nullptr};
@@ -84,8 +85,9 @@ struct bbp_ctx {
     uint8_t gens_enc_host_valid = 0;
     std::vector<uint8_t> mimc_host;    // 90 * 32
     // grow-only scratch
-    bbp::DevBuf scal, idx, sorted, pts, enc, misc, batch[PROVE_BUFS + 1], io_in, io_out, io_ent, raw[2];  // batch[3]: the verifier's; raw[i]: draw buffer of opening stream i
+    bbp::DevBuf scal, idx, sorted, pts, enc, misc, batch[PROVE_BUFS + 1], io_in, io_out, io_ent, raw[2], agg, agg_io;  // batch[3]: the verifier's; raw[i]: draw buffer of opening stream i
     bbp::DevBuf slice_sorted[MAX_SLICES], slice_pts[MAX_SLICES], slice_fold[MAX_SLICES], slice_vtab[MAX_SLICES];  // per-slice MSM scratch (slice 0 uses sorted / pts)
+    int32_t* agg_gstatus = nullptr;  // per-group verdicts of the last aggregated verification (inside agg)
     std::map<uint32_t, void*> circuits;  // N -> CircuitDev* (compiled blind-bid circuit tables on the device)
     std::vector<float> timings;
     // optional per-kernel HIP-event timing (bbp_set_profiling): (tag, start, stop) on the launch stream

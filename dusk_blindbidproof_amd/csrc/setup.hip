@@ -114,6 +114,7 @@ extern "C" int32_t bbp_init(int32_t device, bbp_ctx** out) {
     }
     BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_last, hipEventDisableTiming));
     if (const char* e = getenv("BBP_DUAL_OPEN_BELOW")) ctx->dual_open_below = atoi(e);
+    if (const char* e = getenv("BBP_VARBASE_LANES")) ctx->varbase_lanes = atoi(e) < 64 ? 64 : atoi(e);
     if (const char* e = getenv("BBP_TAIL_ROUND")) ctx->tail_round = atoi(e) == bbp::FOLD_ROUND ? bbp::FOLD_ROUND : 12;
     if (const char* e = getenv("BBP_STAGGER")) ctx->stagger_mode = atoi(e);
     if (const char* e = getenv("BBP_SERIAL_BLOCK")) ctx->serial_block = atoi(e) == 64 ? 64 : atoi(e) == 128 ? 128 : 256;
@@ -167,7 +168,7 @@ extern "C" void bbp_free(bbp_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     void* ptrs[] = {ctx->gens, ctx->ptable, ctx->btab, ctx->slice_fold[0].p, ctx->slice_fold[1].p, ctx->slice_fold[2].p, ctx->slice_fold[3].p,
-                    ctx->slice_vtab[0].p, ctx->slice_vtab[1].p, ctx->slice_vtab[2].p, ctx->slice_vtab[3].p, ctx->comb, ctx->mimc_c, ctx->scal.p, ctx->idx.p, ctx->sorted.p, ctx->pts.p, ctx->enc.p, ctx->misc.p, ctx->batch[0].p, ctx->io_in.p, ctx->io_out.p, ctx->io_ent.p, ctx->raw[0].p, ctx->raw[1].p, ctx->batch[1].p, ctx->batch[2].p, ctx->batch[3].p, ctx->slice_sorted[1].p, ctx->slice_sorted[2].p, ctx->slice_sorted[3].p, ctx->slice_pts[1].p, ctx->slice_pts[2].p, ctx->slice_pts[3].p};
+                    ctx->slice_vtab[0].p, ctx->slice_vtab[1].p, ctx->slice_vtab[2].p, ctx->slice_vtab[3].p, ctx->comb, ctx->mimc_c, ctx->scal.p, ctx->idx.p, ctx->sorted.p, ctx->pts.p, ctx->enc.p, ctx->misc.p, ctx->batch[0].p, ctx->io_in.p, ctx->io_out.p, ctx->io_ent.p, ctx->raw[0].p, ctx->raw[1].p, ctx->agg.p, ctx->agg_io.p, ctx->batch[1].p, ctx->batch[2].p, ctx->batch[3].p, ctx->slice_sorted[1].p, ctx->slice_sorted[2].p, ctx->slice_sorted[3].p, ctx->slice_pts[1].p, ctx->slice_pts[2].p, ctx->slice_pts[3].p};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& kv : ctx->circuits) {  // compiled circuits (one per list length used)

@@ -110,6 +110,18 @@ int32_t bbp_prove_batch_dev(bbp_ctx* ctx, uint32_t B, uint32_t N, const void* in
 int32_t bbp_verify_batch_dev(bbp_ctx* ctx, uint32_t B, uint32_t N, const void* in_dev, const void* entropy_dev, void* status_dev,
                              void* stream);
 
+/* Aggregated verification -- SURVEY.md 8f-4, an extension: the reference verifies one proof per call (verify.rs:88) and has
+ * no equivalent.  Proofs are checked in groups of `group` (0 = BBP_AGG_GROUP_DEFAULT) with ONE generator MSM per group: the
+ * per-proof mega-checks are summed with random weights drawn from each proof's verifier TranscriptRng (seeded by the OS /
+ * entropy_dev).  Every group that fails is re-verified proof by proof, so status[] is what bbp_verify_batch reports (a bad
+ * proof slipping through needs a ~2^-250 accident).  Same record layout as bbp_verify_batch.  *n_fallback (may be NULL)
+ * receives how many proofs went through the per-proof path.  The _dev variant synchronises `stream` before it returns. */
+#define BBP_AGG_GROUP_DEFAULT 32u
+int32_t bbp_verify_batch_aggregated(bbp_ctx* ctx, uint32_t B, uint32_t N, const uint8_t* in, int32_t* status, uint32_t group,
+                                    uint32_t* n_fallback);
+int32_t bbp_verify_batch_aggregated_dev(bbp_ctx* ctx, uint32_t B, uint32_t N, const void* in_dev, const void* entropy_dev,
+                                        void* status_dev, uint32_t group, uint32_t* n_fallback, void* stream);
+
 /* Parity hook: the 32-scalar challenge block of proof `proof` of the LAST batch call of geometry (B, N):
  * y z u x w y^-1 t1..t6 tb1..tb6 t_x t_x~ e~ ... (MiscSlot order in csrc/batch.h), 32 x 32 bytes. */
 int32_t bbp_debug_challenges(bbp_ctx* ctx, uint32_t B, uint32_t N, uint32_t proof, uint8_t* out32x32);

@@ -229,6 +229,44 @@ def test_verify_large_batch_with_corruptions(ctx, bbp):
     assert all(got[i] in (1, 3) for i in bad)
 
 
+@pytest.mark.parametrize("group", [0, 7, 1000])
+def test_aggregated_verification_reports_per_proof_statuses(ctx, bbp, group):
+    """SURVEY.md 8f-4 extension: groups of proofs share one weighted generator MSM; failing groups are re-verified proof by
+    proof.  The statuses must be exactly those of the per-proof path for every kind of rejection (bad proof bytes, wrong public
+    input, non-canonical scalar -> FormatError, undecodable / identity point), also with several bad proofs in one group, a
+    ragged last group and one group spanning the whole batch; an all-honest batch must not take the per-proof path at all."""
+    N, distinct, B = 3, 24, 203
+    ins, ents, vins = _synth_batch(ctx, distinct, N, seed=808)
+    out, st = ctx.prove_batch(distinct, N, b"".join(ins), b"".join(ents))
+    assert st == [0] * distinct
+    rs_ = bbp.record_size(N)
+    rows = [bytearray(out[(i % distinct) * rs_:(i % distinct + 1) * rs_] + b"".join(vins[i % distinct])) for i in range(B)]
+    honest = b"".join(bytes(r) for r in rows)
+    got, nfb = ctx.verify_batch_aggregated(B, N, honest, group)
+    assert got == [0] * B and nfb == 0
+    kinds = {}
+    for j, i in enumerate(sorted({(k * 29 + 3) % B for k in range(17)} | {8, 9, 10, B - 1})):  # 8, 9, 10: neighbours in one group
+        kind = j % 5
+        if kind == 0:
+            rows[i][1 + 32 * 14 + 5] ^= 0x10             # a bit of an IPA point / scalar region
+        elif kind == 1:
+            rows[i][rs_ + 3] ^= 1                        # wrong score (public input)
+        elif kind == 2:
+            rows[i][1 + 32 * 8:1 + 32 * 9] = b"\xff" * 32   # t_x non-canonical -> FormatError
+        elif kind == 3:
+            rows[i][1:33] = b"\xff" * 32                 # A_I1 is not a valid ristretto encoding
+        else:
+            rows[i][1 + 32:1 + 64] = bytes(32)           # A_O1 = identity encoding: validate_and_append_point rejects
+        kinds[i] = kind
+    blob = b"".join(bytes(r) for r in rows)
+    plain = ctx.verify_batch(B, N, blob)
+    assert sorted(i for i, v in enumerate(plain) if v != 0) == sorted(kinds)
+    assert all(plain[i] == 3 for i, k in kinds.items() if k == 2)
+    got, nfb = ctx.verify_batch_aggregated(B, N, blob, group)
+    assert got == plain
+    assert 0 < nfb <= B
+
+
 def test_calls_from_different_streams_are_serialised(ctx, oc, bbp):
     """One context shares scratch between calls; calls issued on different caller streams must still be ordered (stream guard).
     Regression: two chunks in flight on two streams once raced on the MSM scratch and faulted the GPU."""
@@ -270,6 +308,8 @@ def test_calls_from_different_streams_are_serialised(ctx, oc, bbp):
     {"BBP_SLICES": "1", "BBP_SERIAL_LDS": "0"},                 # one heavy-stage stream, serial kernels not fenced off
     {"BBP_SLICES": "4", "BBP_SERIAL_BLOCK": "256"},             # four slices (two of them share a hardware queue by default)
     {"BBP_SLICES": "2", "BBP_STAGGER": "1"},
+    {"BBP_VARBASE_LANES": "1000", "BBP_DUAL_OPEN_BELOW": "0"},  # verifier: 3 lanes per proof, ~15 points per lane on one doubling chain
+    {"BBP_VARBASE_LANES": "64"},                                # verifier: one lane per proof
 ])
 def test_engine_schedules_give_identical_bytes(bbp, oc, knobs):
     """The scheduling knobs (slices, tail round, serial-kernel fencing, stagger) change WHEN and HOW work runs, never the bytes:
