@@ -321,7 +321,9 @@ __global__ BBP_LANE_KERNEL void k_tr_yz(u32 B, u32 m, const u32* __restrict__ en
 }
 
 // out[p][e] = base[p]^e for e in [0, count): one lane per chunk of 32 exponents
-__global__ BBP_LANE_KERNEL void k_powers(u32 B, u32 count, const sc* __restrict__ misc, int slot, sc* __restrict__ out, u32 out_stride) {
+// mont_out = 0: out[e] = x^e;  1: out[e] = x^e R (Montgomery form, for consumers that multiply by it once).  Either way one
+// Montgomery multiplication per power: cur * (x R) * R^-1 = cur * x keeps cur in whichever domain it started in.
+__global__ BBP_LANE_KERNEL void k_powers(u32 B, u32 count, const sc* __restrict__ misc, int slot, sc* __restrict__ out, u32 out_stride, u32 mont_out) {
     BBP_THIN_PRIO();
     const u32 chunks = (count + 31) / 32;
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -329,11 +331,12 @@ __global__ BBP_LANE_KERNEL void k_powers(u32 B, u32 count, const sc* __restrict_
     u32 p = t / chunks, c = t % chunks;
     sc x = ld_sc(&misc[(size_t)p * MS_COUNT + slot]);
     sc xm = sc_to_mont(x);
-    sc cur = sc_to_mont(sc_pow_small(x, c * 32));
+    sc cur = sc_pow_small(x, c * 32);
+    if (mont_out) cur = sc_to_mont(cur);
     sc* o = out + (size_t)p * out_stride;
     u32 end = min(count, c * 32 + 32);
     for (u32 e = c * 32; e < end; e++) {
-        st_sc(&o[e], sc_from_mont(cur));
+        st_sc(&o[e], cur);
         cur = sc_montmul(cur, xm);
     }
 }
@@ -1155,9 +1158,9 @@ static int32_t prove_heavy(bbp_ctx* ctx, const CircuitDev& c, const BatchDev& bd
     for (u32 k = 0; k < 3; k++)
         LAUNCH(ctx, TAG_ENCODE, k_encode_strided, cdiv(B, 64), 64, s, B, 1u, tmp + (size_t)k * B, 1u, bd.enc, encw, 8 * (m + k));
     LAUNCH(ctx, TAG_TRANSCRIPT, k_tr_yz, cdiv(B, 64), 64, s, B, m, bd.enc, bd.tr, bd.misc);
-    LAUNCH(ctx, TAG_POLY, k_powers, cdiv(B * cdiv(c.n_cons + 1, 32), 64), 64, s, B, c.n_cons + 1, bd.misc, (int)MS_Z, bd.zpow, c.n_cons + 1);
-    LAUNCH(ctx, TAG_POLY, k_powers, cdiv(B * cdiv(2049, 32), 64), 64, s, B, 2049u, bd.misc, (int)MS_Y, bd.ypow, 2049u);
-    LAUNCH(ctx, TAG_POLY, k_powers, cdiv(B * cdiv(2048, 32), 64), 64, s, B, 2048u, bd.misc, (int)MS_YINV, bd.yipow, 2048u);
+    LAUNCH(ctx, TAG_POLY, k_powers, cdiv(B * cdiv(c.n_cons + 1, 32), 64), 64, s, B, c.n_cons + 1, bd.misc, (int)MS_Z, bd.zpow, c.n_cons + 1, 0u);
+    LAUNCH(ctx, TAG_POLY, k_powers, cdiv(B * cdiv(2049, 32), 64), 64, s, B, 2049u, bd.misc, (int)MS_Y, bd.ypow, 2049u, 0u);
+    LAUNCH(ctx, TAG_POLY, k_powers, cdiv(B * cdiv(2048, 32), 64), 64, s, B, 2048u, bd.misc, (int)MS_YINV, bd.yipow, 2048u, 0u);
     const u32 n_tgt = 3 * n1 + m;
     LAUNCH(ctx, TAG_POLY, k_flatten, cdiv(B * n_tgt, 128), 128, s, B, n_tgt, n1, m, c.f_off, c.f_ent, bd.zpow, c.n_cons + 1, bd.wl, bd.wr,
            bd.wo, bd.wv, 2048u);
