@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- blind-bid Bulletproofs hot path on MI355X (one process per GPU).
 
-    python bench.py --gpus N --steps K --warmup W [--workload prove|verify|msm] [--batch B] [--items N_ITEMS]
+    python bench.py --gpus N --steps K --warmup W [--workload prove|verify|verify_aggregated|msm] [--batch B] [--items N_ITEMS]
 
 A "step" is one pass of the hot path over one batch of B synthetic bids whose inputs are already resident in HBM.
   workload prove (default): BASELINE.json configs[2] -- full R1CS prove of B = 1024 bids (gadget witness, Merlin, commitment
@@ -124,7 +124,7 @@ def main():
     if world > 1:
         dist.barrier()
     import dusk_blindbidproof_amd as bbp
-    from bench_workloads import make_workload, MsmWorkload, VerifyWorkload
+    from bench_workloads import make_workload, MsmWorkload, VerifyWorkload, VerifyAggregatedWorkload
 
     ctx = bbp.Context(dev_index)
     wl = make_workload(args.workload, ctx, bbp, torch, device, args.batch, args.items, seed=1 + rank)
@@ -144,8 +144,8 @@ def main():
 
     also = {}
     if args.workload == "prove" and not args.no_also:
-        for name, cls in (("verify", VerifyWorkload), ("msm_stage", MsmWorkload)):
-            kw = {"prove_wl": wl} if cls is VerifyWorkload else {}
+        for name, cls in (("verify", VerifyWorkload), ("verify_aggregated", VerifyAggregatedWorkload), ("msm_stage", MsmWorkload)):
+            kw = {"prove_wl": wl} if issubclass(cls, VerifyWorkload) else {}
             w2 = cls(ctx, bbp, torch, device, args.batch, args.items, 1 + rank, **kw)
             w2.step(stream)
             torch.cuda.synchronize()

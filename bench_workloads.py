@@ -286,6 +286,29 @@ class VerifyWorkload(_Base):
                 "sample": "%d verifications (C oracle, %d threads) in %.1f s" % (sample, threads, dt)}
 
 
+class VerifyAggregatedWorkload(VerifyWorkload):
+    """The same B verifications (1 % corrupted) through bbp_verify_batch_aggregated_dev: groups of 32 proofs share one weighted
+    generator MSM, the members of failing groups are re-verified one by one; statuses as the per-proof path reports them.
+    The call synchronises the stream itself (the host reads the group verdicts)."""
+
+    metric = "blind-bid verifies/sec (aggregated, SURVEY 8f-4 extension)"
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.group = 32
+        self.n_fallback = 0
+        self.config = dict(self.config, workload=self.config["workload"] + ", aggregated in groups of %d with per-proof fallback" % self.group)
+
+    def step(self, stream):
+        self.n_fallback = self.ctx.verify_batch_aggregated_dev(self.B, self.N, self.in_dev.data_ptr(), self.ent_dev.data_ptr(),
+                                                               self.status.data_ptr(), self.group, stream)
+        # MSMs the engine actually ran: one per group plus one per re-verified proof
+        n_msm = (self.B + self.group - 1) // self.group + self.n_fallback
+        self.row_additions_per_step = n_msm * 4098 * NAF12_DIGITS
+        self.dominant_launches_per_step = 2 if self.n_fallback else 1
+        self.config["reverified_per_step"] = self.n_fallback
+
+
 def make_workload(name, ctx, bbp, torch, device, batch, items, seed):
     if name in ("auto", "prove"):
         return ProveWorkload(ctx, bbp, torch, device, batch, items, seed)
@@ -293,4 +316,6 @@ def make_workload(name, ctx, bbp, torch, device, batch, items, seed):
         return MsmWorkload(ctx, bbp, torch, device, batch, items, seed)
     if name == "verify":
         return VerifyWorkload(ctx, bbp, torch, device, batch, items, seed)
+    if name == "verify_aggregated":
+        return VerifyAggregatedWorkload(ctx, bbp, torch, device, batch, items, seed)
     raise SystemExit("unknown workload %r" % name)
