@@ -35,6 +35,7 @@ SIGNATURES = {
     "bbp_verify_batch": (_i32, [_vp, _u32, _u32, _vp, _vp]),
     "bbp_prove_batch_dev": (_i32, [_vp, _u32, _u32, _vp, _vp, _vp, _vp]),
     "bbp_verify_batch_dev": (_i32, [_vp, _u32, _u32, _vp, _vp, _vp, _vp]),
+    "bbp_prepare_bids_dev": (_i32, [_vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "bbp_verify_batch_aggregated": (_i32, [_vp, _u32, _u32, _vp, _vp, _u32, _vp]),
     "bbp_verify_batch_aggregated_dev": (_i32, [_vp, _u32, _u32, _vp, _vp, _vp, _u32, _vp, _vp]),
     "bbp_debug_challenges": (_i32, [_vp, _u32, _u32, _u32, _vp]),
@@ -160,6 +161,10 @@ class Context:
         status = (ctypes.c_int32 * B)()
         self._check(lib.bbp_verify_batch(self._h, B, N, _buf(inputs), status))
         return list(status)
+
+    def prepare_bids_dev(self, B, N, bids_ptr, lists_ptr, toggles_ptr, prove_in_ptr, verify_tail_ptr=None, stream=0):
+        """Device-side caller pass: (d,k,seed) + bid list + toggle -> rows for prove_batch_dev / the tail of verify_batch_dev rows."""
+        self._check(lib.bbp_prepare_bids_dev(self._h, B, N, bids_ptr, lists_ptr, toggles_ptr, prove_in_ptr, verify_tail_ptr, stream))
 
     def verify_batch_aggregated(self, B, N, inputs, group=0):
         """Statuses as verify_batch; proofs are checked in groups of `group` (0 = default 32) with one generator MSM per group,

@@ -43,6 +43,45 @@ __global__ void k_witness_native(u32 B, const u8* __restrict__ dks, const sc* __
     st_sc(&o[5], z);
 }
 
+// the caller-side pass (Go, upstream of Proof::prove) on the device, writing the prover's and the verifier's
+// input rows directly.  One lane per bid.  bids: d || k || seed (96 B); lists: N x 32 B (entry `toggle` is replaced by the
+// bid's own x); toggles: u64.  prove_in row: d,k,y,y_inv,q,z_img,seed || list || toggle; verify_tail row: q || z_img || seed || list.
+__global__ void k_prepare_bids(u32 B, u32 N, const u8* __restrict__ bids, const u8* __restrict__ lists, const u64* __restrict__ toggles,
+                               const sc* __restrict__ mimc, u32* __restrict__ prove_in, u32* __restrict__ verify_tail) {
+    u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= B) return;
+    const u32* in = reinterpret_cast<const u32*>(bids + 96 * (size_t)p);
+    sc d = sc_reduce256(in), k = sc_reduce256(in + 8), seed = sc_reduce256(in + 16);
+    sc m = mimc_native(k, sc_zero(), mimc);
+    sc x = mimc_native(d, m, mimc);
+    sc y = mimc_native(seed, x, mimc);
+    sc z = mimc_native(seed, m, mimc);
+    sc yi = sc_invert(y);
+    sc q = sc_mul(d, yi);
+    const u64 toggle = toggles[p];
+    const size_t pw = 7 * 8 + (size_t)N * 8 + 2, vw = 3 * 8 + (size_t)N * 8;  // row lengths in words
+    u32* o = prove_in + pw * p;
+    const sc seven[7] = {d, k, y, yi, q, z, seed};
+    for (int i = 0; i < 7; i++)
+        for (int w = 0; w < 8; w++) o[8 * i + w] = seven[i].v[w];
+    o[56 + 8 * N] = (u32)toggle;
+    o[56 + 8 * N + 1] = (u32)(toggle >> 32);
+    u32* v = verify_tail ? verify_tail + vw * p : nullptr;
+    if (v)
+        for (int w = 0; w < 8; w++) {
+            v[w] = q.v[w];
+            v[8 + w] = z.v[w];
+            v[16 + w] = seed.v[w];
+        }
+    const u32* li = reinterpret_cast<const u32*>(lists + 32 * (size_t)N * p);
+    for (u32 i = 0; i < N; i++)
+        for (int w = 0; w < 8; w++) {
+            const u32 word = (u64)i == toggle ? x.v[w] : li[8 * i + w];
+            o[56 + 8 * i + w] = word;
+            if (v) v[24 + 8 * i + w] = word;
+        }
+}
+
 static bool os_random(uint8_t* buf, size_t n) {
     FILE* f = fopen("/dev/urandom", "rb");
     if (!f) return false;
@@ -73,6 +112,27 @@ extern "C" int32_t bbp_witness_batch(bbp_ctx* ctx, uint32_t B, const uint8_t* dk
     }
     BBP_HIP_TRY(ctx, hipMemcpyAsync(out, ctx->io_out.p, 192 * (size_t)B, hipMemcpyDeviceToHost, ctx->stream));
     BBP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return BBP_OK;
+}
+
+static int32_t check_n(bbp_ctx* ctx, uint32_t N);
+extern "C" int32_t bbp_prepare_bids_dev(bbp_ctx* ctx, uint32_t B, uint32_t N, const void* bids_dev, const void* lists_dev,
+                                        const void* toggles_dev, void* prove_in_dev, void* verify_tail_dev, void* stream) {
+    if (!ctx || !bids_dev || !lists_dev || !toggles_dev || !prove_in_dev) return BBP_ERR_BAD_ARG;
+    int32_t rc = check_n(ctx, N);
+    if (rc) return rc;
+    if (B == 0) return BBP_OK;
+    BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    {
+        ScopedEvent ev(ctx, TAG_WITNESS, s);
+        hipLaunchKernelGGL(k_prepare_bids, dim3((B + 63) / 64), dim3(64), 0, s, B, N, (const u8*)bids_dev, (const u8*)lists_dev,
+                           (const u64*)toggles_dev, ctx->mimc_c, (u32*)prove_in_dev, (u32*)verify_tail_dev);
+        BBP_HIP_TRY(ctx, hipGetLastError());
+    }
+    // the prover's opening stage does not wait for the caller's stream (bbp.h); it does wait for this event
+    BBP_HIP_TRY(ctx, hipEventRecord(ctx->ev_prep, s));
+    ctx->ev_prep_valid = true;
     return BBP_OK;
 }
 

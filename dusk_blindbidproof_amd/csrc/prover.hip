@@ -1086,6 +1086,10 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
         // NOTE the opening stage does NOT wait for the caller's stream: in_dev / ent_dev must be complete when the call is
         // made (include/bbp.h).  Waiting on the caller's stream tail would serialise it behind the previous call's heavy stage.
         if (ctx->ev_done_valid[par]) BBP_HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_done[par], 0));
+        if (ctx->ev_prep_valid) {  // rows written by bbp_prepare_bids_dev since the last prove call
+            BBP_HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_prep, 0));
+            ctx->ev_prep_valid = false;
+        }
         LAUNCH(ctx, TAG_WITNESS, k_fill_mimc, cdiv(B * BBP_MIMC_ROUNDS, 64), 64, s, B, c.n_cst, ctx->mimc_c, bd.cst);
         if ((rc = serial_lds_bytes(ctx, (const void*)k_open_serial))) return rc;
         const u32 hog = ctx->serial_lds > 0 ? (u32)ctx->serial_lds : 0u;

@@ -113,6 +113,7 @@ extern "C" int32_t bbp_init(int32_t device, bbp_ctx** out) {
         BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_stagger[i - 1], hipEventDisableTiming));
     }
     BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_last, hipEventDisableTiming));
+    BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming));
     if (const char* e = getenv("BBP_DUAL_OPEN_BELOW")) ctx->dual_open_below = atoi(e);
     if (const char* e = getenv("BBP_VARBASE_LANES")) ctx->varbase_lanes = atoi(e) < 64 ? 64 : atoi(e);
     if (const char* e = getenv("BBP_TAIL_ROUND")) ctx->tail_round = atoi(e) == bbp::FOLD_ROUND ? bbp::FOLD_ROUND : 12;
@@ -191,6 +192,7 @@ extern "C" void bbp_free(bbp_ctx* ctx) {
         if (ctx->lane[i]) (void)hipStreamDestroy(ctx->lane[i]);
     }
     if (ctx->ev_last) (void)hipEventDestroy(ctx->ev_last);
+    if (ctx->ev_prep) (void)hipEventDestroy(ctx->ev_prep);
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
     if (ctx->side2) (void)hipStreamDestroy(ctx->side2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -75,6 +75,17 @@ int32_t bbp_msm_batch_dev(bbp_ctx* ctx, uint32_t B, uint32_t n_terms, const void
  * the device.  in: B * 96 bytes (d,k,seed); out: B * 192 bytes (m,x,y,y_inv,q,z_img). */
 int32_t bbp_witness_batch(bbp_ctx* ctx, uint32_t B, const uint8_t* dks, uint8_t* out);
 
+/* the caller-side pass on the device, feeding the batch prover / verifier directly (all pointers device
+ * pointers, `stream` a hipStream_t, no synchronisation).  Per bid: bids_dev 96 B (d,k,seed as for bbp_witness_batch), lists_dev
+ * N*32 B (the public bid list; entry `toggle` is overwritten with the bid's own x = mimc(d, mimc(k,0))), toggles_dev u64 (< N,
+ * caller's responsibility).  Writes prove_in_dev rows in bbp_prove_batch_dev's input layout (7*32 + N*32 + 8 bytes) and, unless
+ * NULL, verify_tail_dev rows score || z_img || seed || pub_list (96 + N*32 bytes) -- what follows the record in a
+ * bbp_verify_batch row.  The next bbp_prove_batch_dev on this context waits for these rows by itself (the one exception to
+ * "inputs must be complete at call time" below); anything else that reads them must be ordered after `stream` by the caller.
+ * Give it a stream of its own when proving back to back: on the prover's stream it would queue behind the previous batch. */
+int32_t bbp_prepare_bids_dev(bbp_ctx* ctx, uint32_t B, uint32_t N, const void* bids_dev, const void* lists_dev,
+                             const void* toggles_dev, void* prove_in_dev, void* verify_tail_dev, void* stream);
+
 /* Replaces Proof::prove (src/blindbid/proof.rs:36-46).
  * scalars7 = d,k,y,y_inv,q,z_img,seed; pub_list = N*32 bytes (Scalar::from_bits semantics, src/blindbid/bid.rs:27);
  * entropy = (4+N)*32 bytes of commitment blindings + 32 bytes rng seed (replaces thread_rng, proof.rs:53-64), or NULL

@@ -201,6 +201,51 @@ def test_batch_geometries_and_buffer_regrowth(ctx, oc, bbp, B, N):
     assert out2 == out
 
 
+@pytest.mark.parametrize("N,B", [(8, 70), (1, 5), (5, 33)])
+def test_prepare_bids_on_device_feeds_prove_and_verify(ctx, oc, bbp, N, B):
+    """(d, k, seed) + bid list + toggle -> prover rows and verifier tails on the device, byte-equal to the rows the
+    host assembles from bbp_witness_batch (whose values the oracle tests pin); the rows then go straight into the device prover
+    and verifier without touching the host."""
+    import torch
+    dev = torch.device("cuda", 0)
+    ins, ents, vins = _synth_batch(ctx, B, N, seed=5150 + N)
+    bids = b"".join(r[:64] + r[192:224] for r in ins)                                 # d || k || seed
+    lists = bytearray(b"".join(r[224:224 + 32 * N] for r in ins))
+    toggles = [int.from_bytes(r[-8:], "little") for r in ins]
+    for i, t in enumerate(toggles):
+        lists[32 * (N * i + t):32 * (N * i + t + 1)] = b"\xee" * 32                  # the bid's own slot is filled in on the device
+    d_bids = torch.frombuffer(bytearray(bids), dtype=torch.uint8).to(dev)
+    d_lists = torch.frombuffer(lists, dtype=torch.uint8).to(dev)
+    d_tog = torch.tensor(toggles, dtype=torch.int64, device=dev)
+    in_stride, rs_ = 224 + 32 * N + 8, bbp.record_size(N)
+    vt_stride = 96 + 32 * N
+    d_in = torch.zeros(B * in_stride, dtype=torch.uint8, device=dev)
+    d_vt = torch.zeros(B * vt_stride, dtype=torch.uint8, device=dev)
+    d_ent = torch.frombuffer(bytearray(b"".join(ents)), dtype=torch.uint8).to(dev)
+    d_out = torch.zeros(B * rs_, dtype=torch.uint8, device=dev)
+    vin = torch.empty((B, rs_ + vt_stride), dtype=torch.uint8, device=dev)
+    vent = torch.zeros(B * 32, dtype=torch.uint8, device=dev)
+    status = torch.full((B,), -1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    # no host synchronisation from here on: the bid pass on a stream of its own (as a pipelined caller would run it), prove /
+    # verify on another (a real stream: handle 0 would mean the context's internal stream, which torch's copies are not ordered with)
+    prep, main = torch.cuda.Stream(), torch.cuda.Stream()
+    ctx.prepare_bids_dev(B, N, d_bids.data_ptr(), d_lists.data_ptr(), d_tog.data_ptr(), d_in.data_ptr(), d_vt.data_ptr(), prep.cuda_stream)
+    with torch.cuda.stream(main):
+        ctx.prove_batch_dev(B, N, d_in.data_ptr(), d_ent.data_ptr(), d_out.data_ptr(), main.cuda_stream)  # orders itself after the bid pass
+        main.wait_stream(prep)  # for the copy of the verifier tails
+        vin[:, :rs_] = d_out.view(B, rs_)
+        vin[:, rs_:] = d_vt.view(B, vt_stride)
+        ctx.verify_batch_dev(B, N, vin.data_ptr(), vent.data_ptr(), status.data_ptr(), main.cuda_stream)
+    torch.cuda.synchronize()
+    assert bytes(d_in.cpu().numpy().tobytes()) == b"".join(ins)
+    assert bytes(d_vt.cpu().numpy().tobytes()) == b"".join(b"".join(v) for v in vins)
+    out = bytes(d_out.cpu().numpy().tobytes())
+    rc, exp = oc.prove(ins[B - 1][:224], ins[B - 1][224:224 + 32 * N], toggles[B - 1], ents[B - 1])
+    assert rc == 0 and out[(B - 1) * rs_:] == exp
+    assert status.cpu().tolist() == [0] * B
+
+
 def test_batch_status_per_item(ctx, bbp):
     ins, ents, _ = _synth_batch(ctx, 4, 3, seed=77)
     bad_toggle = bytearray(ins[1])
