@@ -82,6 +82,15 @@ __global__ void k_prepare_bids(u32 B, u32 N, const u8* __restrict__ bids, const 
         }
 }
 
+// proofs per engine call when a host-pointer batch API is handed more (BBP_HOST_CHUNK_PROVE / BBP_HOST_CHUNK_VERIFY)
+static uint32_t env_chunk(const char* name, uint32_t dflt) {
+    const char* e = getenv(name);
+    const long v = e ? atol(e) : 0;
+    return v >= 1 ? (uint32_t)v : dflt;
+}
+static uint32_t host_chunk_prove() { return env_chunk("BBP_HOST_CHUNK_PROVE", 16384); }
+static uint32_t host_chunk_verify() { return env_chunk("BBP_HOST_CHUNK_VERIFY", 32768); }
+
 static bool os_random(uint8_t* buf, size_t n) {
     FILE* f = fopen("/dev/urandom", "rb");
     if (!f) return false;
@@ -203,7 +212,16 @@ extern "C" int32_t bbp_prove_batch(bbp_ctx* ctx, uint32_t B, uint32_t N, const u
     BBP_HIP_TRY(ctx, hipMemcpyAsync(ctx->io_in.p, src, in_stride * B, hipMemcpyHostToDevice, ctx->stream));
     BBP_HIP_TRY(ctx, hipMemcpyAsync(ctx->io_ent.p, entropy, ent_stride * B, hipMemcpyHostToDevice, ctx->stream));
     BBP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors may go out of scope
-    if ((rc = prove_batch_dev(ctx, B, N, (const u8*)ctx->io_in.p, (const u8*)ctx->io_ent.p, (u8*)ctx->io_out.p, ctx->stream))) return rc;
+    // Very large host batches go through the engine in equal chunks of at most host_chunk_prove proofs so that scratch stays
+    // bounded (~1.3 MB per proof of the largest call, three buffers); consecutive calls pipeline -- chunk k+1's opening stage
+    // under chunk k's MSMs.  One 16384-proof call was measured 5 % faster than four of 4096, hence the large default.
+    const uint32_t n_chunks = (B + host_chunk_prove() - 1) / host_chunk_prove(), chunk = (B + n_chunks - 1) / n_chunks;
+    for (uint32_t first = 0; first < B; first += chunk) {
+        const uint32_t nb = B - first < chunk ? B - first : chunk;
+        if ((rc = prove_batch_dev(ctx, nb, N, (const u8*)ctx->io_in.p + in_stride * first, (const u8*)ctx->io_ent.p + ent_stride * first,
+                                  (u8*)ctx->io_out.p + out_stride * first, ctx->stream)))
+            return rc;
+    }
     BBP_HIP_TRY(ctx, hipMemcpyAsync(out, ctx->io_out.p, out_stride * B, hipMemcpyDeviceToHost, ctx->stream));
     BBP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (uint32_t i = 0; i < B; i++)
@@ -259,13 +277,18 @@ static int32_t verify_batch_host(bbp_ctx* ctx, uint32_t B, uint32_t N, uint32_t 
     BBP_HIP_TRY(ctx, hipMemcpyAsync(ctx->io_in.p, in, stride * B, hipMemcpyHostToDevice, ctx->stream));
     BBP_HIP_TRY(ctx, hipMemcpyAsync(ctx->io_ent.p, ent.data(), ent.size(), hipMemcpyHostToDevice, ctx->stream));
     BBP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (group > 1) {
-        if ((rc = verify_batch_agg_dev(ctx, B, N, group, (const u8*)ctx->io_in.p, (const u8*)ctx->io_ent.p, (int32_t*)ctx->io_out.p,
-                                       ctx->stream, n_fallback)))
+    const uint32_t n_chunks = (B + host_chunk_verify() - 1) / host_chunk_verify(), chunk = (B + n_chunks - 1) / n_chunks;
+    for (uint32_t first = 0; first < B; first += chunk) {  // bounded scratch for any B (see bbp_prove_batch)
+        const uint32_t nb = B - first < chunk ? B - first : chunk;
+        const u8 *cin = (const u8*)ctx->io_in.p + stride * first, *cent = (const u8*)ctx->io_ent.p + 32 * (size_t)first;
+        int32_t* cst = (int32_t*)ctx->io_out.p + first;
+        if (group > 1) {
+            uint32_t nf = 0;
+            if ((rc = verify_batch_agg_dev(ctx, nb, N, group, cin, cent, cst, ctx->stream, &nf))) return rc;
+            if (n_fallback) *n_fallback += nf;
+        } else if ((rc = verify_batch_dev_ex(ctx, nb, N, rec_ver, 0, cin, cent, cst, ctx->stream)))
             return rc;
-    } else if ((rc = verify_batch_dev_ex(ctx, B, N, rec_ver, 0, (const u8*)ctx->io_in.p, (const u8*)ctx->io_ent.p, (int32_t*)ctx->io_out.p,
-                                         ctx->stream)))
-        return rc;
+    }
     BBP_HIP_TRY(ctx, hipMemcpyAsync(status, ctx->io_out.p, 4 * (size_t)B, hipMemcpyDeviceToHost, ctx->stream));
     BBP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return BBP_OK;

@@ -246,6 +246,32 @@ def test_prepare_bids_on_device_feeds_prove_and_verify(ctx, oc, bbp, N, B):
     assert status.cpu().tolist() == [0] * B
 
 
+def test_host_batches_are_chunked_transparently(ctx, bbp, monkeypatch):
+    """The host-pointer batch calls cut large batches into equal engine calls (BBP_HOST_CHUNK_*, default 16384 / 32768): records
+    and statuses must not depend on the chunking, including ragged last chunks and rejected items."""
+    N, B = 2, 131
+    ins, ents, vins = _synth_batch(ctx, B, N, seed=606)
+    bad = bytearray(ins[77])
+    bad[-8:] = (N).to_bytes(8, "little")                                  # toggle == N -> BAD_ARG, zeroed record
+    ins[77] = bytes(bad)
+    ref, rst = ctx.prove_batch(B, N, b"".join(ins), b"".join(ents))
+    assert rst == [0] * 77 + [4] + [0] * (B - 78)
+    rs_ = bbp.record_size(N)
+    rows = [bytearray(ref[i * rs_:(i + 1) * rs_] + b"".join(vins[i])) for i in range(B)]
+    rows[5][40] ^= 2
+    rows[130][rs_ + 1] ^= 1
+    blob = b"".join(bytes(r) for r in rows)
+    vref = ctx.verify_batch(B, N, blob)
+    assert [i for i, v in enumerate(vref) if v] == [5, 77, 130]
+    monkeypatch.setenv("BBP_HOST_CHUNK_PROVE", "50")                      # 3 chunks of 44, 44, 43
+    monkeypatch.setenv("BBP_HOST_CHUNK_VERIFY", "60")
+    out, st = ctx.prove_batch(B, N, b"".join(ins), b"".join(ents))
+    assert st == rst and out == ref
+    assert ctx.verify_batch(B, N, blob) == vref
+    got, nfb = ctx.verify_batch_aggregated(B, N, blob, 8)
+    assert got == vref and nfb > 0
+
+
 def test_batch_status_per_item(ctx, bbp):
     ins, ents, _ = _synth_batch(ctx, 4, 3, seed=77)
     bad_toggle = bytearray(ins[1])
