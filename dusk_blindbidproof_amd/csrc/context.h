@@ -89,6 +89,7 @@ struct bbp_ctx {
     // grow-only scratch
     bbp::DevBuf scal, idx, sorted, pts, enc, misc, batch[PROVE_BUFS + 1], io_in, io_out, io_ent, raw[2], agg, agg_io;  // batch[3]: the verifier's; raw[i]: draw buffer of opening stream i
     bbp::DevBuf slice_sorted[MAX_SLICES], slice_pts[MAX_SLICES], slice_fold[MAX_SLICES], slice_vtab[MAX_SLICES];  // per-slice MSM scratch (slice 0 uses sorted / pts)
+    void *agg_vs = nullptr, *agg_varsum = nullptr;  // weighted generator scalars [B][4098] / per-proof variable-base sums of that pass
     int32_t* agg_gstatus = nullptr;  // per-group verdicts of the last aggregated verification (inside agg)
     std::map<uint32_t, void*> circuits;  // N -> CircuitDev* (compiled blind-bid circuit tables on the device)
     std::vector<float> timings;

@@ -124,9 +124,9 @@ int32_t bbp_verify_batch_dev(bbp_ctx* ctx, uint32_t B, uint32_t N, const void* i
 /* Aggregated verification -- SURVEY.md 8f-4, an extension: the reference verifies one proof per call (verify.rs:88) and has
  * no equivalent.  Proofs are checked in groups of `group` (0 = BBP_AGG_GROUP_DEFAULT) with ONE generator MSM per group: the
  * per-proof mega-checks are summed with random weights drawn from each proof's verifier TranscriptRng (seeded by the OS /
- * entropy_dev).  Every group that fails is re-verified proof by proof, so status[] is what bbp_verify_batch reports (a bad
- * proof slipping through needs a ~2^-250 accident).  Same record layout as bbp_verify_batch.  *n_fallback (may be NULL)
- * receives how many proofs went through the per-proof path.  The _dev variant synchronises `stream` before it returns. */
+ * entropy_dev).  The members of every group that fails are then checked one by one (an MSM each over the scalars already
+ * computed), so status[] is what bbp_verify_batch reports (a bad proof slipping through needs a ~2^-250 accident).  Same record layout as bbp_verify_batch.  *n_fallback (may be NULL)
+ * receives how many proofs were checked individually.  The _dev variant synchronises `stream` before it returns. */
 #define BBP_AGG_GROUP_DEFAULT 32u
 int32_t bbp_verify_batch_aggregated(bbp_ctx* ctx, uint32_t B, uint32_t N, const uint8_t* in, int32_t* status, uint32_t group,
                                     uint32_t* n_fallback);
