@@ -76,6 +76,7 @@ def _kernel_table(timings):
 # average non-zero digits per scalar of the engine's recodings (tests/test_host_arith.py::test_naf_recoding measures them):
 # width-12 NAF in the <0> MSM kernels, width-9 NAF in the <1> (generator fold) instances; one digit = one table-row addition
 NAF12_DIGITS, NAF9_DIGITS = 19.85, 25.66
+MERGED_AI_TERMS = 4 * 90 * 4  # A_I1 terms that ride on another term's merged base (prover.hip circuit_get), any N
 
 
 # HBM bytes per accumulate-kernel launch (k_msm_acc, a third of the batch per launch) from the rocprofv3 PMC passes on B = 1024,
@@ -173,7 +174,9 @@ class ProveWorkload(_Base):
         # what the engine's MSM kernels actually add (fold-free IPA: rounds 1-6 are 2 x 2049-term MSMs over the original generators,
         # then one composite-bucket pass over all 4096 generators; the tail rounds are variable-base work outside the MSM kernels)
         # (round 1 walks the 2048 - n1 zero-padded multipliers' common-scalar terms of L as ONE term on a precomputed sum)
-        engine_terms = commit_terms + 6 * 2 * 2049 - max(2048 - n1 - 1, 0)
+        # (A_I1: the 4 x 90 MiMC rounds wire a to three multiplier inputs and a^2 to three more; each triple is ONE term on a merged
+        #  base, MERGED_AI_TERMS terms fewer -- DESIGN.md "Merged bases")
+        engine_terms = commit_terms - MERGED_AI_TERMS + 6 * 2 * 2049 - max(2048 - n1 - 1, 0)
         self.row_additions_per_step = batch * (engine_terms * NAF12_DIGITS + 4096 * NAF9_DIGITS)
         self.dominant_launches_per_step = 3 + 6 + 1
         self.measured_traffic_bytes = None  # set from profiles/ (rocprofv3 PMC passes) for the B = 1024, N = 8 configuration

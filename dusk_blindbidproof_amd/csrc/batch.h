@@ -16,7 +16,9 @@ struct CircuitDev {  // compiled circuit tables resident on the device (one per 
     u32 n_items = 0, m = 0, n_mul = 0, n_cons = 0, padded = 0, n_cst = 0;
     u32 *w_terms = nullptr, *w_loff = nullptr, *w_roff = nullptr, *f_off = nullptr, *f_ent = nullptr, *c_q = nullptr, *c_cst = nullptr;
     u32 n_cterms = 0;
-    u32* idx_ai = nullptr;   // base indices of A_I1 / S1 terms: B_blinding, G[0..n1), H[0..n1)
+    u32* idx_ai = nullptr;   // base indices of A_I1's terms: B_blinding, G[0..n1), H[0..n1), equal-valued inputs merged (circuit_get)
+    u32* idx_s1 = nullptr;   // the same layout unmerged, for S1 (independent random scalars)
+    u32 n_ai_terms = 0;      // terms of A_I1 that are not skipped
     u32* idx_ao = nullptr;   // B_blinding, G[0..n1)
     u32* idx_ipa = nullptr;  // [11 rounds][2 (L,R)][2049]
     u32* idx_ver = nullptr;  // verifier fixed part: G[0..2048), H[0..2048), B, B_blinding

@@ -38,7 +38,13 @@ constexpr int FOLD_K = FOLD_CLS * FOLD_M;  // 4096 composite buckets
 // b[i] h[i - 1024] = -y^1024 for every i): 582 table-row walks become one (prover.hip k_ipa_round, circuit_get).
 constexpr int PAD_BASES = 202;                             // one per list length N = 1..202
 constexpr unsigned PAD_BASE0 = BBP_NUM_BASES;
-constexpr unsigned TAB_BASES = BBP_NUM_BASES + PAD_BASES;  // bases with rows in ptable
+// Merged bases for multiplier inputs that always carry the same value (the MiMC rounds wire a to L_i, R_i, R_{i+1} and a^2 to
+// L_{i+1}, L_{i+2}, R_{i+2}: circuit_get): MRG1(i) = G[i] + H[i] + H[i+1], MRG2(i) = G[i] + G[i+1] + H[i+1], i = 0..2046 --
+// A_I1 then needs one term where it had three.
+constexpr unsigned MRG_BASE0 = PAD_BASE0 + PAD_BASES;
+constexpr int MRG_BASES = 2 * 2048;
+constexpr unsigned MSM_SKIP_BASE = 0xffffffffu;            // index-list entry: this term's scalar rides on another term's merged base
+constexpr unsigned TAB_BASES = BBP_NUM_BASES + PAD_BASES + MRG_BASES;  // bases with rows in ptable
 constexpr int GE_WORDS = sizeof(ge) / 4;  // 40: a point in registers / LDS / scratch
 
 struct DevBuf {
@@ -79,8 +85,8 @@ struct bbp_ctx {
     bool ev_last_valid = false;
     std::string err;
     // resident tables
-    bbp::ge* gens = nullptr;           // [TAB_BASES] extended points: B_blinding, G[2048], H[2048], B, then the PAD_BASES range sums
-    bbp::niels_row* ptable = nullptr;      // [TAB_BASES * MSM_POS] affine cached 2^b * P_i, 128-byte limb rows (141 MB)
+    bbp::ge* gens = nullptr;           // [TAB_BASES] extended points: B_blinding, G[2048], H[2048], B, then the PAD_BASES range sums and the MRG_BASES merged bases
+    bbp::niels_row* ptable = nullptr;      // [TAB_BASES * MSM_POS] affine cached 2^b * P_i, 128-byte limb rows (275 MB)
     bbp::ge* btab = nullptr;               // [32] m * 2^(64 k) * B, m = 1..8, k = 0..3 (prover.hip tail rounds)
     bbp::niels_packed* comb = nullptr;     // [2][64][8] radix-16 comb for B and B_blinding (small commits)
     bbp::sc* mimc_c = nullptr;         // [90]

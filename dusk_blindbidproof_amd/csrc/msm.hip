@@ -9,7 +9,7 @@
 // limbs, so a scalar can be recoded in width-12 non-adjacent form: odd digits |d| < 2048 at arbitrary bit positions, one
 // non-zero digit per 13 bits on average (19.5 per scalar instead of the 24 of aligned 11-bit windows), 1024 buckets, and
 // no doublings anywhere.  The hot loop is instruction-issue bound (measured: serving all rows from cache changes its time
-// by 7 %), so fewer additions and no unpacking are what count; the 134 MB of rows are HBM/MALL resident.
+// by 7 %), so fewer additions and no unpacking are what count; the generators' 134 MB of rows (275 MB with the padded-range and merged bases) are HBM/MALL resident.
 //
 // One workgroup owns one MSM, in two kernels (k_msm_sort: 1024 thin lanes, k_msm_acc: 128 fat lanes):
 //   A. NAF digits of every scalar -> LDS histogram over bucket (|d| + 1) / 2
@@ -181,6 +181,7 @@ __global__ __launch_bounds__(SORT_T) void k_msm_sort(const u32* __restrict__ sca
         const uint4* sp = reinterpret_cast<const uint4*>(sbase + (size_t)i * 8);
         uint4 lo = sp[0], hi = sp[1];
         const u32 s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        if (MODE == 0 && base_idx[i] == MSM_SKIP_BASE) continue;  // this scalar rides on another term's merged base
         sc_for_each_naf_digit<NAF>(s, [&](u32, u32 mag, u32) { atomicAdd(&cursor[key(i, mag)], 1u); });
     }
     __syncthreads();
@@ -223,6 +224,7 @@ __global__ __launch_bounds__(SORT_T) void k_msm_sort(const u32* __restrict__ sca
         const uint4* sp = reinterpret_cast<const uint4*>(sbase + (size_t)i * 8);
         uint4 lo = sp[0], hi = sp[1];
         const u32 s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        if (MODE == 0 && base_idx[i] == MSM_SKIP_BASE) continue;
         const u32 tb = (MODE == 0 ? base_idx[i] : base0 + i) * MSM_POS;
         sc_for_each_naf_digit<NAF>(s, [&](u32 pos, u32 mag, u32 neg) {
             u32 at = atomicAdd(&cursor[key(i, mag)], 1u);

@@ -940,6 +940,35 @@ int32_t circuit_get(bbp_ctx* ctx, uint32_t n_items, const CircuitDev** out) {
     ao.push_back(BBP_BASE_BBLIND);
     for (u32 i = 0; i < c.n_mul; i++) ai.push_back(BBP_BASE_G0 + i), ao.push_back(BBP_BASE_G0 + i);
     for (u32 i = 0; i < c.n_mul; i++) ai.push_back(BBP_BASE_H0 + i);
+    const std::vector<u32> s1 = ai;
+    // Multiplier inputs wired to the SAME linear combination always carry the same scalar: where three of them sit as
+    // {L_i, R_i, R_i+1} or {L_i, L_i+1, R_i+1} (every MiMC round has one of each: a and a^2) the first keeps the scalar on the
+    // merged base G/H sum and the other two are skipped by the sort kernel -- 1440 of A_I1's 2933 terms.
+    {
+        const u32 n = c.n_mul;
+        auto side = [&](u32 s) {  // s < n: left input of multiplier s, else right input of multiplier s - n
+            const bool right = s >= n;
+            const u32 i = right ? s - n : s;
+            const u32 b = right ? c.w_roff[i] : c.w_loff[i], e = right ? c.w_loff[i + 1] : c.w_roff[i];
+            return std::vector<u32>(c.w_terms.begin() + b, c.w_terms.begin() + e);
+        };
+        auto same = [&](u32 a, u32 b, u32 d) { return side(a) == side(b) && side(a) == side(d); };
+        std::vector<char> used(2 * n, 0);
+        for (u32 i = 0; i + 1 < n; i++) {
+            const u32 Li = i, Ri = n + i, Li1 = i + 1, Ri1 = n + i + 1;
+            if (!used[Li] && !used[Ri] && !used[Ri1] && same(Li, Ri, Ri1)) {
+                ai[1 + Li] = MRG_BASE0 + i;
+                ai[1 + Ri] = ai[1 + Ri1] = MSM_SKIP_BASE;
+                used[Li] = used[Ri] = used[Ri1] = 1;
+            } else if (!used[Li] && !used[Li1] && !used[Ri1] && same(Li, Li1, Ri1)) {
+                ai[1 + Li] = MRG_BASE0 + 2048 + i;
+                ai[1 + Li1] = ai[1 + Ri1] = MSM_SKIP_BASE;
+                used[Li] = used[Li1] = used[Ri1] = 1;
+            }
+        }
+        d->n_ai_terms = 0;
+        for (u32 v : ai) d->n_ai_terms += v != MSM_SKIP_BASE;
+    }
     // IPA round r (1-based), n = 1024 >> (r-1): term rank = blk*n + io of block blk = k / 2n
     for (u32 r = 1; r <= 11; r++) {
         const u32 n = 1024u >> (r - 1);
@@ -963,7 +992,7 @@ int32_t circuit_get(bbp_ctx* ctx, uint32_t n_items, const CircuitDev** out) {
     for (u32 i = 0; i < 2048; i++) ver.push_back(BBP_BASE_H0 + i);
     ver.push_back(BBP_BASE_B);
     ver.push_back(BBP_BASE_BBLIND);
-    if ((rc = upload(ctx, ai, &d->idx_ai)) || (rc = upload(ctx, ao, &d->idx_ao)) || (rc = upload(ctx, ipa, &d->idx_ipa)) ||
+    if ((rc = upload(ctx, ai, &d->idx_ai)) || (rc = upload(ctx, s1, &d->idx_s1)) || (rc = upload(ctx, ao, &d->idx_ao)) || (rc = upload(ctx, ipa, &d->idx_ipa)) ||
         (rc = upload(ctx, ver, &d->idx_ver)))
         return rc;
     ctx->circuits[n_items] = d;
@@ -1155,7 +1184,7 @@ static int32_t prove_heavy(bbp_ctx* ctx, const CircuitDev& c, const BatchDev& bd
     if ((rc = msm_launch(ctx, B, 1 + 2 * n1, (const u32*)bd.ai1, c.idx_ai, tmp, s, 1, slot))) return rc;
     if (stagger && ctx->stagger_mode == 1) BBP_HIP_TRY(ctx, hipEventRecord(stagger, s));
     if ((rc = msm_launch(ctx, B, 1 + n1, (const u32*)bd.ao1, c.idx_ao, tmp + B, s, 1, slot))) return rc;
-    if ((rc = msm_launch(ctx, B, 1 + 2 * n1, (const u32*)bd.s1, c.idx_ai, tmp + 2 * (size_t)B, s, 1, slot))) return rc;
+    if ((rc = msm_launch(ctx, B, 1 + 2 * n1, (const u32*)bd.s1, c.idx_s1, tmp + 2 * (size_t)B, s, 1, slot))) return rc;
     // the next slice starts once this one has issued its three commitment MSMs: its own commitment MSMs then run under this
     // slice's long MSM-free stretch (encode, transcript, powers, flatten, poly, T commitments, l/r vectors)
     if (stagger && ctx->stagger_mode == 3) BBP_HIP_TRY(ctx, hipEventRecord(stagger, s));

@@ -39,6 +39,21 @@ __global__ void k_pad_sums(ge* __restrict__ gens) {
     }
 }
 
+// merged bases (context.h): MRG1(i) = G[i] + H[i] + H[i+1] at MRG_BASE0 + i, MRG2(i) = G[i] + G[i+1] + H[i+1] at MRG_BASE0 + 2048 + i
+__global__ void k_merge_sums(ge* __restrict__ gens) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2048u) return;
+    const ge g = gens[BBP_BASE_G0 + i];
+    if (i == 2047u) {  // no neighbour: never referenced, any valid point will do
+        gens[MRG_BASE0 + i] = g;
+        gens[MRG_BASE0 + 2048 + i] = g;
+        return;
+    }
+    const ge h1 = gens[BBP_BASE_H0 + i + 1];
+    gens[MRG_BASE0 + i] = ge_add(ge_add(g, gens[BBP_BASE_H0 + i]), h1);
+    gens[MRG_BASE0 + 2048 + i] = ge_add(ge_add(g, gens[BBP_BASE_G0 + i + 1]), h1);
+}
+
 // thread (i, c): rows 16c .. 16c+15 of generator i: table[i*256 + b] = affine cached form of 2^b * gens[i]
 constexpr int PT_CHUNK = 16;
 __global__ void k_build_ptable(const ge* __restrict__ gens, niels_row* __restrict__ table) {
@@ -154,6 +169,8 @@ extern "C" int32_t bbp_init(int32_t device, bbp_ctx** out) {
     BBP_HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_pad_sums, dim3(1), dim3(64), 0, ctx->stream, ctx->gens);
     BBP_HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_merge_sums, dim3(2048 / 64), dim3(64), 0, ctx->stream, ctx->gens);
+    BBP_HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_build_ptable, dim3((TAB_BASES * (MSM_POS / PT_CHUNK) + 63) / 64), dim3(64), 0, ctx->stream, ctx->gens, ctx->ptable);
     BBP_HIP_TRY(ctx, hipGetLastError());
     if (int32_t rc = tail_btab_build(ctx)) return rc;
@@ -175,7 +192,7 @@ extern "C" void bbp_free(bbp_ctx* ctx) {
     for (auto& kv : ctx->circuits) {  // compiled circuits (one per list length used)
         bbp::CircuitDev* c = static_cast<bbp::CircuitDev*>(kv.second);
         if (!c) continue;
-        void* cp[] = {c->w_terms, c->w_loff, c->w_roff, c->f_off, c->f_ent, c->c_q, c->c_cst, c->idx_ai, c->idx_ao, c->idx_ipa, c->idx_ver};
+        void* cp[] = {c->w_terms, c->w_loff, c->w_roff, c->f_off, c->f_ent, c->c_q, c->c_cst, c->idx_ai, c->idx_s1, c->idx_ao, c->idx_ipa, c->idx_ver};
         for (void* p : cp)
             if (p) (void)hipFree(p);
         delete c;

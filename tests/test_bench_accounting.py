@@ -22,10 +22,11 @@ def test_engine_addition_counts_are_consistent():
     n1 = 1466
     commit_terms = (1 + 2 * n1) * 2 + (1 + n1)
     assert commit_terms == 7333
-    engine_terms = commit_terms + 6 * 2 * 2049 - (2048 - n1 - 1)
-    assert engine_terms == 31340                       # + 4096 generator-fold terms = 35 436
+    assert bw.MERGED_AI_TERMS == 1440                   # two triples -> two terms in each of the 4 x 90 MiMC rounds
+    engine_terms = commit_terms - bw.MERGED_AI_TERMS + 6 * 2 * 2049 - (2048 - n1 - 1)
+    assert engine_terms == 29900                       # + 4096 generator-fold terms = 33 996
     adds = engine_terms * bw.NAF12_DIGITS + 4096 * bw.NAF9_DIGITS
-    assert 7.0e5 < adds < 7.6e5                         # ~0.73 M mixed additions per proof
+    assert 6.8e5 < adds < 7.2e5                         # ~0.70 M mixed additions per proof
 
 
 def test_measured_traffic_constant_is_per_launch_bytes():
