@@ -82,7 +82,7 @@ MERGED_AI_TERMS = 4 * 90 * 4  # A_I1 terms that ride on another term's merged ba
 # HBM bytes per accumulate-kernel launch (k_msm_acc, a third of the batch per launch) from the rocprofv3 PMC passes on B = 1024,
 # N = 8 (profiles/r01_rocprofv3_pmc_hbm.csv, weighted over the <0> and <1> instances): FETCH_SIZE x 2 (gfx950 reports half of
 # wide reads, MI355X_MICROARCH.md HBM section) + WRITE_SIZE
-MEASURED_TRAFFIC_PROVE_1024_8 = (2 * 1714396 + 508698) * 1024
+MEASURED_TRAFFIC_PROVE_1024_8 = (2 * 1651238 + 508352) * 1024
 
 
 class _Base:
