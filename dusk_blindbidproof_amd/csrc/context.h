@@ -74,6 +74,8 @@ struct bbp_ctx {
     hipEvent_t ev_open[PROVE_BUFS] = {nullptr, nullptr, nullptr}, ev_done[PROVE_BUFS] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_entry[PROVE_BUFS] = {nullptr, nullptr, nullptr};  // caller's stream at entry of a prove call: out_dev is not written before it
     bool ev_done_valid[PROVE_BUFS] = {false, false, false}, ev_open_valid[PROVE_BUFS] = {false, false, false};
+    hipEvent_t ev_vfork = nullptr, ev_vjoin = nullptr;  // verifier: variable-base kernel on lane[1] beside the generator MSM
+    int verify_overlap = 1;                              // BBP_VERIFY_OVERLAP
     hipEvent_t ev_prep = nullptr;  // end of the last bbp_prepare_bids_dev: the next prove call's opening stage waits for it
     bool ev_prep_valid = false;
     uint32_t seq = 0;

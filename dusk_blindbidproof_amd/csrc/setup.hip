@@ -129,6 +129,9 @@ extern "C" int32_t bbp_init(int32_t device, bbp_ctx** out) {
     }
     BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_last, hipEventDisableTiming));
     BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming));
+    BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_vfork, hipEventDisableTiming));
+    BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_vjoin, hipEventDisableTiming));
+    if (const char* e = getenv("BBP_VERIFY_OVERLAP")) ctx->verify_overlap = atoi(e) != 0;
     if (const char* e = getenv("BBP_DUAL_OPEN_BELOW")) ctx->dual_open_below = atoi(e);
     if (const char* e = getenv("BBP_VARBASE_LANES")) ctx->varbase_lanes = atoi(e) < 64 ? 64 : atoi(e);
     if (const char* e = getenv("BBP_TAIL_ROUND")) ctx->tail_round = atoi(e) == bbp::FOLD_ROUND ? bbp::FOLD_ROUND : 12;
@@ -210,6 +213,8 @@ extern "C" void bbp_free(bbp_ctx* ctx) {
     }
     if (ctx->ev_last) (void)hipEventDestroy(ctx->ev_last);
     if (ctx->ev_prep) (void)hipEventDestroy(ctx->ev_prep);
+    if (ctx->ev_vfork) (void)hipEventDestroy(ctx->ev_vfork);
+    if (ctx->ev_vjoin) (void)hipEventDestroy(ctx->ev_vjoin);
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
     if (ctx->side2) (void)hipStreamDestroy(ctx->side2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
