@@ -456,6 +456,35 @@ def test_pipelined_calls_of_mixed_batch_sizes(bbp, oc):
         c2.close()
 
 
+def test_pipelined_calls_with_different_list_lengths(ctx, oc, bbp):
+    """Consecutive device calls with different N use different compiled circuits (index lists, constraint tables) while the
+    previous call is still in flight: outputs must equal the solo runs and the oracle's record."""
+    import torch
+    dev = torch.device("cuda", 0)
+    sets = []
+    for k, (B, N) in enumerate(((40, 2), (33, 9), (70, 1), (25, 30))):
+        ins, ents, _ = _synth_batch(ctx, B, N, seed=1200 + k)
+        d_in = torch.frombuffer(bytearray(b"".join(ins)), dtype=torch.uint8).to(dev)
+        d_ent = torch.frombuffer(bytearray(b"".join(ents)), dtype=torch.uint8).to(dev)
+        solo, st = ctx.prove_batch(B, N, b"".join(ins), b"".join(ents))
+        assert st == [0] * B
+        rs_ = bbp.record_size(N)
+        rc, exp = oc.prove(ins[0][:224], ins[0][224:224 + 32 * N], int.from_bytes(ins[0][-8:], "little"), ents[0])
+        assert rc == 0 and solo[:rs_] == exp
+        sets.append((B, N, d_in, d_ent, solo))
+    torch.cuda.synchronize()
+    main = torch.cuda.Stream()
+    outs = []
+    for it in range(12):
+        B, N, d_in, d_ent, solo = sets[(it * 3) % 4]
+        out = torch.zeros(B * bbp.record_size(N), dtype=torch.uint8, device=dev)
+        ctx.prove_batch_dev(B, N, d_in.data_ptr(), d_ent.data_ptr(), out.data_ptr(), main.cuda_stream)
+        outs.append((out, solo))
+    torch.cuda.synchronize()
+    for it, (out, solo) in enumerate(outs):
+        assert bytes(out.cpu().numpy().tobytes()) == solo, it
+
+
 def test_config3_full_batch(ctx, oc, bbp):
     """SURVEY.md 8d config 3 at full size: 1024 full proves (N = 8) in one batch call; the first 16 and the last 4 records
     byte-compared with the C oracle under the same entropy, every proof accepted by the device verifier, a spread sample of 48
