@@ -76,6 +76,7 @@ struct bbp_ctx {
     bool ev_done_valid[PROVE_BUFS] = {false, false, false}, ev_open_valid[PROVE_BUFS] = {false, false, false};
     hipEvent_t ev_vfork = nullptr, ev_vjoin = nullptr;  // verifier: variable-base kernel on lane[1] beside the generator MSM
     int verify_overlap = 1;                              // BBP_VERIFY_OVERLAP
+    uint32_t seq_at_last_verify = 0;                     // prover call counter seen by the last verification (interleaving test)
     hipEvent_t ev_prep = nullptr;  // end of the last bbp_prepare_bids_dev: the next prove call's opening stage waits for it
     bool ev_prep_valid = false;
     uint32_t seq = 0;
