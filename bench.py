@@ -1,17 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- blind-bid Bulletproofs hot path on MI355X (one process per GPU).
 
-    python bench.py --gpus N --steps K --warmup W [--workload prove|verify|verify_aggregated|msm] [--batch B] [--items N_ITEMS]
+    python bench.py --gpus N --steps K --warmup W [--workload prove|verify|verify_aggregated|msm|stream] [--batch B] [--items N_ITEMS]
 
 A "step" is one pass of the hot path over one batch of B synthetic bids whose inputs are already resident in HBM.
   workload prove (default): BASELINE.json configs[2] -- full R1CS prove of B = 1024 bids (gadget witness, Merlin, commitment
                    MSMs, polynomial sweep, 11 IPA rounds), proof records out.  `value` = proofs/s.
-  workload verify: B full verifications (one 4098-term fixed-base MSM + ~45 proof points each).
+  workload verify: B full verifications (one 4098-term fixed-base MSM + ~45 proof points each); `--batch 8192` is one GPU's
+                   shard of BASELINE.json configs[3] (65 536 verifications over 8 GPUs, flags gathered to rank 0).
   workload msm   : configs[1] -- per proof only the three commitment MSMs A_I1/A_O1/S1 (2933 + 1467 + 2933 terms at N = 8).
-After the timed region the default run also measures the other two workloads for a few steps and reports them as
-`also` (same JSON line), so one run carries proofs/s, verifies/s and the MSM-stage rate.
+  workload stream: configs[4] -- sustained ingest: bids arrive in pinned host memory, each step pushes one chunk of B bids
+                   through H2D copy -> witness -> prove -> verify -> D2H with no host synchronisation on the chunk itself;
+                   reports sustained proofs/s (= verifies/s) and p50 / p99 chunk latency.  PCIe-inclusive by nature.
+After the timed region the default run also measures the other workloads for a few steps and reports them as `also` (same
+JSON line), so one run carries proofs/s, verifies/s and the MSM-stage rate.
 Each rank works on its own B proofs (independent units, no data-path collective; weak scaling); the only collective is the
 final gather of proof records / flags to rank 0.  cpu_baseline (rank 0, N=1 only) times the C oracle on the host cores.
+
+Launch: `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts N ranks itself (fresh child processes,
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, backend nccl = RCCL) before this process has touched the GPU, relays rank 0's JSON
+line and fails if any rank fails or the line does not say n_gpus == N.  Under torchrun (WORLD_SIZE set) it is one of the ranks;
+--gpus must then equal WORLD_SIZE.
 """
 import os
 
@@ -23,7 +32,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import argparse
 import json
-import os
+import subprocess
 import sys
 import time
 
@@ -31,6 +40,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+STUB = os.environ.get("BBP_BENCH_STUB") == "1"  # launcher-plumbing test on a CPU box: gloo, no engine, NOT a measurement
 
 
 def synth_scalars_device(torch, n_rows, n_terms, seed, device):
@@ -48,17 +58,22 @@ def timed(wl, ctx, torch, dist, world, steps, stream):
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
-    ctx.set_profiling(True)
-    ctx.last_timings()
+        if not STUB:
+            torch.cuda.synchronize()
+    if ctx is not None:
+        ctx.set_profiling(True)
+        ctx.last_timings()
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
         wl.step(stream)
+    wl.drain()
     barrier()
     dt = time.perf_counter() - t0
-    timings = ctx.last_timings()
-    ctx.set_profiling(False)
+    timings = []
+    if ctx is not None:
+        timings = ctx.last_timings()
+        ctx.set_profiling(False)
     return dt, timings
 
 
@@ -66,13 +81,18 @@ def roofline(wl, timings, steps, alu_peak=None, wall_s=None):
     dom = [us for tag, us in timings if tag == wl.dominant_tag]
     avg_us = sum(dom) / max(len(dom), 1)
     # algorithmic bytes of the step's dominant-kernel work, spread over the launches that were actually observed
-    # (the engine may cut a batch into half-batches on two streams, doubling the launch count)
+    # (the engine may cut a batch into slices on several streams, multiplying the launch count)
     alg_per_launch = wl.alg_bytes_per_step * steps / max(len(dom), 1)
     achieved = alg_per_launch / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
+    traffic, traffic_src = wl.measured_traffic()
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-           "traffic": wl.measured_traffic_bytes, "kernel": wl.dominant_kernel, "avg_launch_us": avg_us, "launches": len(dom),
+           "traffic": traffic, "traffic_source": traffic_src, "kernel": wl.dominant_kernel, "avg_launch_us": avg_us, "launches": len(dom),
            "alg_bytes_per_launch": alg_per_launch,
-           "note": "modular-integer path: the binding roofline is 32-bit integer multiply issue, not HBM (DESIGN.md section 5)"}
+           "note": "modular-integer path: the binding roofline is 32-bit integer multiply issue, not HBM (DESIGN.md section 5); "
+                   "avg_launch_us is co-residency-stretched when slices overlap -- the exclusive figure is in the named profile"}
+    if traffic and wall_s and dom:
+        # measured HBM-side bytes of the dominant kernel over the WALL time of the region (launches x traffic per launch)
+        out["hbm_side_GBps_whole_step"] = traffic * len(dom) / wall_s / 1e9
     if alu_peak:
         # secondary, honest roofline (SURVEY.md 7 hard part 2): table-row additions the MSM kernels actually perform per second
         # (one per non-zero NAF digit) against the register-resident mixed-addition rate bbp_ubench measures live (no memory traffic)
@@ -86,6 +106,79 @@ def roofline(wl, timings, steps, alu_peak=None, wall_s=None):
     return out
 
 
+def launch_ranks(args, argv):
+    """--gpus N > 1 without a launcher: start N fresh ranks (this process has not touched the GPU), relay rank 0's JSON line."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    if not args.no_build and not STUB:
+        build_all()  # once, in the parent, before any rank exists; the ranks then only check
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv + ["--no-build"], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    # rank 0's stdout is drained on a thread while this loop watches every rank: one rank dying must not leave the others (and
+    # this process) waiting in a rendezvous or barrier forever
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            time.sleep(2.0)  # let the others notice by themselves first
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.05)
+    rcs = [p.wait() for p in procs]
+    reader.join(timeout=10)
+    out0 = b"".join(chunks).decode()
+    if any(rcs):
+        sys.stderr.write("bench.py: rank exit codes %r\n" % rcs)
+        sys.stdout.write(out0)
+        return 1
+    lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
+    if len(lines) != 1:
+        sys.stderr.write("bench.py: expected ONE JSON line from rank 0, got %d\n" % len(lines))
+        return 1
+    if json.loads(lines[0]).get("n_gpus") != args.gpus:
+        sys.stderr.write("bench.py: rank 0 reports n_gpus=%r, --gpus=%d\n" % (json.loads(lines[0]).get("n_gpus"), args.gpus))
+        return 1
+    print(lines[0], flush=True)
+    return 0
+
+
+def build_all(check_only=False):
+    """Compile (or, with check_only, insist on up-to-date) native artefacts.  Runs BEFORE the first torch.cuda / HIP call of this
+    process, under a file lock so that concurrently started ranks build once: a profiler's preloaded library must never see this
+    process spawn a compiler after the GPU is initialised (tools/profile_round.sh passes --no-build)."""
+    import fcntl
+    import __graft_entry__ as ge
+    if check_only:
+        stale = ge.stale_artefacts()
+        if stale:
+            raise SystemExit("bench.py --no-build: stale or missing artefacts %r (run `python __graft_entry__.py` first)" % stale)
+        return
+    with open(os.path.join(ROOT, ".build.lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        ge.build_hip()
+        ge.build_oracle()
+
+
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -96,19 +189,28 @@ def main():
     ap.add_argument("--items", type=int, default=8, help="bid-list length N (SURVEY.md 8d default 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary verify / msm-stage measurements")
+    ap.add_argument("--no-build", action="store_true", help="do not compile anything: fail if the native artefacts are stale")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to report a run of a different size" % (args.gpus, world))
+    if not STUB:
+        build_all(check_only=args.no_build)  # before anything touches the GPU
 
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # rehearsal knobs (one-GPU box): BBP_BENCH_BACKEND=gloo BBP_BENCH_DEVICE=0 run N ranks against a single card
-    backend = os.environ.get("BBP_BENCH_BACKEND", "nccl")
+    backend = "gloo" if STUB else os.environ.get("BBP_BENCH_BACKEND", "nccl")
     dev_index = int(os.environ.get("BBP_BENCH_DEVICE", local_rank))
-    torch.cuda.set_device(dev_index)
-    device = torch.device("cuda", dev_index)
+    device = torch.device("cpu") if STUB else torch.device("cuda", dev_index)
+    if not STUB:
+        torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -117,24 +219,28 @@ def main():
             dist.init_process_group(backend=backend)
     red_dev = device if backend == "nccl" else torch.device("cpu")
 
-    import __graft_entry__ as ge
-    if rank == 0:
-        ge.build_hip()
-        ge.build_oracle()
-    if world > 1:
-        dist.barrier()
-    import dusk_blindbidproof_amd as bbp
-    from bench_workloads import make_workload, MsmWorkload, VerifyWorkload, VerifyAggregatedWorkload
-
-    ctx = bbp.Context(dev_index)
-    wl = make_workload(args.workload, ctx, bbp, torch, device, args.batch, args.items, seed=1 + rank)
-    stream = torch.cuda.current_stream().cuda_stream
+    from bench_workloads import make_workload, MsmWorkload, VerifyWorkload, VerifyAggregatedWorkload, StubWorkload
+    if STUB:
+        if os.environ.get("BBP_BENCH_STUB_FAIL_RANK") == str(rank):
+            sys.exit(3)  # tests/test_bench_launcher.py: a dying rank must fail the whole launch
+        ctx, bbp, wl, stream, engine_stream = None, None, StubWorkload(args.batch), None, None
+    else:
+        import dusk_blindbidproof_amd as bbp
+        ctx = bbp.Context(dev_index)
+        wl = make_workload(args.workload, ctx, bbp, torch, device, args.batch, args.items, seed=1 + rank)
+        # a real caller stream (not handle 0): the ordering contract of include/bbp.h is exercised, and torch's own work of this
+        # script (copies, clones in the workloads) is issued on the same stream
+        engine_stream = torch.cuda.Stream()
+        torch.cuda.set_stream(engine_stream)
+        stream = engine_stream.cuda_stream
     for _ in range(args.warmup):
         wl.step(stream)
-    torch.cuda.synchronize()
+    wl.drain()
+    if not STUB:
+        torch.cuda.synchronize()
     wl.check()  # parity of the warmed-up output against the oracle on a sample (not timed)
 
-    alu_peak = max(ctx.ubench(3, 8192, 2000) for _ in range(2))  # register-resident ge_madd chains: the integer-ALU ceiling
+    alu_peak = None if STUB else max(ctx.ubench(3, 8192, 2000) for _ in range(2))  # register-resident ge_madd chains: the integer-ALU ceiling
     dt, timings = timed(wl, ctx, torch, dist, world, args.steps, stream)
     tmax = torch.tensor([dt], device=red_dev, dtype=torch.float64)
     if world > 1:
@@ -143,7 +249,7 @@ def main():
     dt = float(tmax.item())
 
     also = {}
-    if args.workload == "prove" and not args.no_also:
+    if args.workload == "prove" and not args.no_also and not STUB:
         for name, cls in (("verify", VerifyWorkload), ("verify_aggregated", VerifyAggregatedWorkload), ("msm_stage", MsmWorkload)):
             kw = {"prove_wl": wl} if issubclass(cls, VerifyWorkload) else {}
             w2 = cls(ctx, bbp, torch, device, args.batch, args.items, 1 + rank, **kw)
@@ -158,7 +264,7 @@ def main():
             also[name] = {"metric": w2.metric, "value": w2.units_per_step * 3 * world / d2, "unit": w2.unit, "steps": 3,
                           "ms_per_step": d2 / 3 * 1e3, "config": w2.config, "roofline": roofline(w2, t2, 3, alu_peak, d2)}
             if rank == 0 and world == 1 and not args.no_cpu_baseline and name == "verify":
-                also[name]["cpu_baseline"] = w2.cpu_baseline()
+                also[name]["cpu_baseline"] = dict(w2.cpu_baseline(), cpu_model=cpu_model())
             del w2
 
     if rank == 0:
@@ -166,16 +272,18 @@ def main():
         out = {
             "metric": wl.metric, "value": units / dt, "unit": wl.unit, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32", "data": "synthetic", "config": wl.config,
-            "roofline": roofline(wl, timings, args.steps, alu_peak, dt),
+            "vs_baseline": None, "dtype": "u32", "data": wl.data, "config": wl.config,
         }
+        if not STUB:
+            out["roofline"] = roofline(wl, timings, args.steps, alu_peak, dt)
         out.update(wl.extra_report(timings))
         if also:
             out["also"] = also
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = wl.cpu_baseline()
+        if world == 1 and not args.no_cpu_baseline and not STUB:
+            out["cpu_baseline"] = dict(wl.cpu_baseline(), cpu_model=cpu_model())
         print(json.dumps(out), flush=True)
-    ctx.close()
+    if ctx is not None:
+        ctx.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

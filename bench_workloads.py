@@ -79,22 +79,55 @@ NAF12_DIGITS, NAF9_DIGITS = 19.85, 25.66
 MERGED_AI_TERMS = 4 * 90 * 4  # A_I1 terms that ride on another term's merged base (prover.hip circuit_get), any N
 
 
-# HBM bytes per accumulate-kernel launch (k_msm_acc, a third of the batch per launch) from the rocprofv3 PMC passes on B = 1024,
-# N = 8 (profiles/r01_rocprofv3_pmc_hbm.csv, weighted over the <0> and <1> instances): FETCH_SIZE x 2 (gfx950 reports half of
-# wide reads, MI355X_MICROARCH.md HBM section) + WRITE_SIZE
-MEASURED_TRAFFIC_PROVE_1024_8 = (2 * 1651238 + 508352) * 1024
+def _traffic_from_profiles(key):
+    """HBM bytes per dominant-kernel launch as MEASURED by the rocprofv3 PMC passes of the named profile (FETCH_SIZE and
+    WRITE_SIZE in separate runs; FETCH_SIZE x 2 on gfx950 per MI355X_MICROARCH.md's HBM section).  The figure is read from
+    profiles/traffic.json, which tools/pmc_aggregate.py writes from the counter CSVs -- not measured in this run, so the bench
+    line names the file it comes from; (None, None) when there is no profile of this workload."""
+    try:
+        import json
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[key]
+        return int(t["bytes_per_launch"]), t["source"]
+    except Exception:
+        return None, None
 
 
 class _Base:
     dominant_tag = 1
     dominant_kernel = "k_msm_acc"
-    measured_traffic_bytes = None
+    traffic_key = None
+    data = "synthetic"
+
+    def measured_traffic(self):
+        return _traffic_from_profiles(self.traffic_key) if self.traffic_key else (None, None)
 
     def extra_report(self, timings):
         return {"kernels_us": _kernel_table(timings)}
 
     def gather(self, dist, rank, world):
         pass
+
+    def drain(self):
+        pass
+
+
+class StubWorkload(_Base):
+    """BBP_BENCH_STUB=1 only: no engine, no GPU -- lets tests/test_bench_launcher.py drive bench.py's N-rank launch path (process
+    start, rendezvous, barrier, max-over-ranks timing, one JSON line) on a CPU box over gloo.  Never a measurement."""
+    metric, unit, data = "stub (launcher plumbing test, not a measurement)", "steps/s", "stub"
+
+    def __init__(self, batch):
+        self.units_per_step = batch
+        self.config = {"workload": "stub: sleeps 1 ms per step", "batch_per_gpu": batch}
+
+    def step(self, stream):
+        time.sleep(0.001)
+
+    def check(self):
+        pass
+
+    def extra_report(self, timings):
+        return {}
 
 
 class MsmWorkload(_Base):
@@ -179,9 +212,7 @@ class ProveWorkload(_Base):
         engine_terms = commit_terms - MERGED_AI_TERMS + 6 * 2 * 2049 - max(2048 - n1 - 1, 0)
         self.row_additions_per_step = batch * (engine_terms * NAF12_DIGITS + 4096 * NAF9_DIGITS)
         self.dominant_launches_per_step = 3 + 6 + 1
-        self.measured_traffic_bytes = None  # set from profiles/ (rocprofv3 PMC passes) for the B = 1024, N = 8 configuration
-        if batch == 1024 and items == 8:
-            self.measured_traffic_bytes = MEASURED_TRAFFIC_PROVE_1024_8
+        self.traffic_key = "prove_b1024_n8" if batch == 1024 and items == 8 else None
         self.config = {"workload": "configs[2]: batch of %d full blind-bid R1CS proves (N=%d, 1466 multipliers, 11 IPA rounds)" % (batch, items),
                        "batch_per_gpu": batch, "bid_list_len": items, "msm_recoding": "NAF-12", "parallelism": "batch-sharded",
                        "ref_msm_terms_per_proof": ref_terms, "engine_msm_terms_per_proof": engine_terms + 4096}
@@ -233,13 +264,15 @@ class VerifyWorkload(_Base):
 
     def __init__(self, ctx, bbp, torch, device, batch, items, seed, prove_wl=None):
         self.ctx, self.bbp, self.torch, self.B, self.N = ctx, bbp, torch, batch, items
-        pw = prove_wl or ProveWorkload(ctx, bbp, torch, device, batch, items, seed)
-        pw.step(0)
+        # BASELINE.json configs[3] allows distinct proofs tiled: at most 1024 are made, larger batches repeat them
+        distinct = min(batch, 1024)
+        pw = prove_wl if prove_wl is not None and prove_wl.B == distinct else ProveWorkload(ctx, bbp, torch, device, distinct, items, seed)
+        pw.step(None)
         torch.cuda.synchronize()
         recs = pw.records()
         rec = pw.rec
         self.stride = rec + 96 + 32 * items
-        rows = [bytearray(recs[i * rec:(i + 1) * rec] + pw.qz[i] + pw.pubs[i]) for i in range(batch)]
+        rows = [bytearray(recs[(i % distinct) * rec:(i % distinct + 1) * rec] + pw.qz[i % distinct] + pw.pubs[i % distinct]) for i in range(batch)]
         self.bad = sorted(set((i * 97 + 13) % batch for i in range(max(batch // 100, 1))))
         for i in self.bad:
             rows[i][100 + (i % 900)] ^= 0x20
@@ -251,8 +284,10 @@ class VerifyWorkload(_Base):
         self.alg_bytes_per_step = batch * ((4135 + items) * 160 + 32)   # verify = 4135 + N terms
         self.row_additions_per_step = batch * 4098 * NAF12_DIGITS      # the fixed-base mega-check MSM launch
         self.dominant_launches_per_step = 1
-        self.config = {"workload": "batch of %d full blind-bid verifications (N=%d), %d corrupted" % (batch, items, len(self.bad)),
-                       "batch_per_gpu": batch, "bid_list_len": items, "parallelism": "batch-sharded"}
+        self.traffic_key = "verify_b%d_n%d" % (batch, items)
+        self.config = {"workload": "%sbatch of %d full blind-bid verifications (N=%d), %d corrupted at known indices, %d distinct proofs"
+                       % ("configs[3] shard: " if batch == 8192 else "", batch, items, len(self.bad), distinct),
+                       "batch_per_gpu": batch, "bid_list_len": items, "parallelism": "batch-sharded, flags gathered to rank 0"}
 
     def step(self, stream):
         self.ctx.verify_batch_dev(self.B, self.N, self.in_dev.data_ptr(), self.ent_dev.data_ptr(), self.status.data_ptr(), stream)
@@ -312,7 +347,142 @@ class VerifyAggregatedWorkload(VerifyWorkload):
         self.config["reverified_per_step"] = self.n_fallback
 
 
+class StreamWorkload(_Base):
+    """BASELINE.json configs[4] on this rank: streaming prove + verify at sustained ingest.  Bids arrive in pinned host memory in
+    the caller's raw form -- (d, k, seed) || bid list || toggle, plus prover entropy -- and one step pushes ONE chunk of B bids
+    through: H2D copies and the witness pass (bbp_prepare_bids_dev) on a copy stream, prove and verify on the engine stream,
+    records + flags D2H into pinned memory.  No host synchronisation on the chunk itself: the host only waits for the slot it is
+    about to reuse (`depth` chunks back).  Chunk latency = device timeline from the chunk's first H2D copy to its last D2H copy.
+    The distinct bids are a tile of 256 (building a million witnesses' inputs in Python would dominate the run); every chunk gets
+    fresh prover entropy, so every proof differs."""
+
+    metric = "blind-bid proofs/sec (streaming prove+verify, host ingest: PCIe-inclusive)"
+    unit = "proofs/s"
+
+    def __init__(self, ctx, bbp, torch, device, batch, items, seed, depth=3):
+        import numpy as np
+        self.np, self.ctx, self.bbp, self.torch, self.B, self.N, self.depth = np, ctx, bbp, torch, batch, items, depth
+        C, N, tile = batch, items, min(batch, 256)
+        sd = _wide(_stream(seed, 0, b"seed"))
+        bids = [_stream(seed, i, b"d")[:8] + bytes(24) + _wide(_stream(seed, i, b"k")) + sd for i in range(tile)]
+        lists = [b"".join(_wide(_stream(seed, i, b"pub%d" % j)) for j in range(N)) for i in range(tile)]
+        ents = [b"".join(_wide(_stream(seed, i, b"ent%d" % j)) for j in range(4 + N)) + bytes(32) for i in range(tile)]
+        pin = lambda data: torch.frombuffer(bytearray(data), dtype=torch.uint8).pin_memory()
+        self.h_bids = pin(b"".join(bids[i % tile] for i in range(C)))
+        self.h_lists = pin(b"".join(lists[i % tile] for i in range(C)))
+        self.h_tog = torch.tensor([i % N for i in range(C)], dtype=torch.int64).pin_memory()
+        self.es, self.rec, self.in_stride, self.vt = bbp.entropy_size(N), bbp.record_size(N), 224 + 32 * N + 8, 96 + 32 * N
+        self.ent_np = np.frombuffer(bytearray(b"".join(ents[i % tile] for i in range(C))), dtype=np.uint8).reshape(C, self.es).copy()
+        self.cp = torch.cuda.Stream()
+        z = lambda n, dt=torch.uint8: torch.zeros(n, dtype=dt, device=device)
+        self.slots = [dict(h_ent=torch.empty(C * self.es, dtype=torch.uint8).pin_memory(), d_bids=z(C * 96), d_lists=z(C * 32 * N),
+                           d_tog=z(C, torch.int64), d_ent=z(C * self.es), d_in=z(C * self.in_stride), d_vt=z(C * self.vt), d_rec=z(C * self.rec),
+                           d_vin=torch.empty((C, self.rec + self.vt), dtype=torch.uint8, device=device), d_vent=z(C * 32),
+                           d_st=torch.full((C,), -1, dtype=torch.int32, device=device),
+                           h_rec=torch.empty(C * self.rec, dtype=torch.uint8).pin_memory(), h_st=torch.empty(C, dtype=torch.int32).pin_memory(),
+                           ev_in=torch.cuda.Event(), ev0=torch.cuda.Event(enable_timing=True), ev1=torch.cuda.Event(enable_timing=True),
+                           busy=False, chunk=-1) for _ in range(depth)]
+        self.k = 0
+        self.lat_ms, self.failed, self.done_chunks = [], 0, 0
+        self.units_per_step = batch
+        n1 = 1442 + 3 * items
+        ref_terms = 2 * (4 + items) + 5 * n1 + 3 + 11 + 8210 + 8188
+        self.alg_bytes_per_step = batch * (ref_terms * 160 + 32 * ((4 + items) + 8 + 22)) + batch * ((4135 + items) * 160 + 32)
+        engine_terms = (1 + 2 * n1) * 2 + (1 + n1) - MERGED_AI_TERMS + 6 * 2 * 2049 - max(2048 - n1 - 1, 0)
+        self.row_additions_per_step = batch * (engine_terms * NAF12_DIGITS + 4096 * NAF9_DIGITS + 4098 * NAF12_DIGITS)
+        self.config = {"workload": "configs[4]: streaming prove+verify at sustained host ingest, chunks of %d bids (N=%d), %d chunk slots"
+                       % (batch, items, depth), "batch_per_gpu": batch, "bid_list_len": items, "parallelism": "batch-sharded",
+                       "ingest": "pinned host memory -> H2D -> witness on device -> prove -> verify -> D2H"}
+
+    def _retire(self, sl):
+        sl["ev1"].synchronize()
+        self.lat_ms.append(sl["ev0"].elapsed_time(sl["ev1"]))
+        self.failed += int((sl["h_st"] != 0).sum())
+        self.done_chunks += 1
+        sl["busy"] = False
+
+    def step(self, stream):
+        torch, C, N = self.torch, self.B, self.N
+        sl = self.slots[self.k % self.depth]
+        if sl["busy"]:
+            self._retire(sl)  # the only host wait: the slot used `depth` chunks ago
+        seeds = self.np.frombuffer(hashlib.shake_256(b"chunk%d" % self.k).digest(32 * C), dtype=self.np.uint8).reshape(C, 32)
+        self.ent_np[:, self.es - 32:] = seeds
+        sl["h_ent"].copy_(torch.from_numpy(self.ent_np.reshape(-1)))
+        eng = torch.cuda.current_stream()
+        with torch.cuda.stream(self.cp):
+            sl["ev0"].record(self.cp)
+            sl["d_bids"].copy_(self.h_bids, non_blocking=True)
+            sl["d_lists"].copy_(self.h_lists, non_blocking=True)
+            sl["d_tog"].copy_(self.h_tog, non_blocking=True)
+            sl["d_ent"].copy_(sl["h_ent"], non_blocking=True)
+            # witness + row assembly on the copy stream: the prover's opening stage waits for this pass by itself (bbp.h), and
+            # it runs behind the entropy copy on the same stream, so every prover input is complete when that stage starts
+            self.ctx.prepare_bids_dev(C, N, sl["d_bids"].data_ptr(), sl["d_lists"].data_ptr(), sl["d_tog"].data_ptr(), sl["d_in"].data_ptr(),
+                                      sl["d_vt"].data_ptr(), self.cp.cuda_stream)
+            sl["ev_in"].record(self.cp)
+        self.ctx.prove_batch_dev(C, N, sl["d_in"].data_ptr(), sl["d_ent"].data_ptr(), sl["d_rec"].data_ptr(), stream)
+        eng.wait_event(sl["ev_in"])  # the verifier tails
+        sl["d_vin"][:, :self.rec] = sl["d_rec"].view(C, self.rec)
+        sl["d_vin"][:, self.rec:] = sl["d_vt"].view(C, self.vt)
+        self.ctx.verify_batch_dev(C, N, sl["d_vin"].data_ptr(), sl["d_vent"].data_ptr(), sl["d_st"].data_ptr(), stream)
+        sl["h_rec"].copy_(sl["d_rec"], non_blocking=True)
+        sl["h_st"].copy_(sl["d_st"], non_blocking=True)
+        sl["ev1"].record(eng)
+        sl["busy"], sl["chunk"] = True, self.k
+        self.k += 1
+
+    def drain(self):
+        for i in range(self.depth):
+            sl = self.slots[(self.k + i) % self.depth]
+            if sl["busy"]:
+                self._retire(sl)
+
+    def check(self):
+        if self.failed:
+            raise SystemExit("stream workload: %d failed verifications" % self.failed)
+        lib = _oracle_lib()
+        sl = self.slots[(self.k - 1) % self.depth]
+        row = bytes(sl["d_in"][:self.in_stride].cpu().numpy().tobytes())
+        ent = bytes(sl["h_ent"][:self.es].numpy().tobytes())
+        rc, exp = lib.prove(row[:224], row[224:224 + 32 * self.N], int.from_bytes(row[-8:], "little"), ent)
+        if rc != 0 or bytes(sl["h_rec"][:self.rec].numpy().tobytes()) != exp:
+            raise SystemExit("PARITY FAILURE in stream workload (chunk %d, record 0)" % sl["chunk"])
+        self.lat_ms.clear()
+
+    def extra_report(self, timings):
+        lat = sorted(self.lat_ms)
+        pick = lambda q: lat[min(len(lat) - 1, int(len(lat) * q))] if lat else None
+        return {"kernels_us": _kernel_table(timings), "failed_verifications": self.failed, "chunks": len(lat),
+                "chunk_latency_ms": {"p50": pick(0.5), "p99": pick(0.99), "max": lat[-1] if lat else None,
+                                     "definition": "device timeline, first H2D copy of the chunk -> last D2H copy of its records and flags"}}
+
+    def gather(self, dist, rank, world):
+        from dusk_blindbidproof_amd import sharding
+        sl = self.slots[(self.k - 1) % self.depth]
+        return sharding.gather_records(dist, sl["d_st"].view(self.torch.uint8), 4, self.B * world, rank, world)
+
+    def cpu_baseline(self):
+        lib = _oracle_lib()
+        threads = host_threads()
+        sample = 2 * threads
+        sl = self.slots[(self.k - 1) % self.depth]
+        ins = bytes(sl["d_in"][:sample * self.in_stride].cpu().numpy().tobytes())
+        ents = bytes(sl["h_ent"][:sample * self.es].numpy().tobytes())
+        t0 = time.perf_counter()
+        recs, st = lib.prove_many(ins, ents, sample, self.N, threads)
+        vt = bytes(sl["d_vt"][:sample * self.vt].cpu().numpy().tobytes())
+        vin = b"".join(recs[i * self.rec:(i + 1) * self.rec] + vt[i * self.vt:(i + 1) * self.vt] for i in range(sample))
+        vst = lib.verify_many(vin, sample, self.N, threads)
+        dt = time.perf_counter() - t0
+        assert st == [0] * sample and vst == [0] * sample
+        return {"value": sample / dt, "unit": self.unit, "cores": threads, "kind": "port",
+                "sample": "%d bids proved then verified (C oracle, one per thread, %d threads) in %.1f s" % (sample, threads, dt)}
+
+
 def make_workload(name, ctx, bbp, torch, device, batch, items, seed):
+    if name == "stream":
+        return StreamWorkload(ctx, bbp, torch, device, batch, items, seed)
     if name in ("auto", "prove"):
         return ProveWorkload(ctx, bbp, torch, device, batch, items, seed)
     if name == "msm":

@@ -4,7 +4,8 @@ The library has no CPU compute path: importing works anywhere (so the C-ABI surf
 `Context()` raises unless a gfx950 device is present, and the import itself raises if the HIP library was not built.
 """
 from ._native import (Context, BbpError, lib, lib_path, STATUS, SIGNATURES, record_size, entropy_size,
-                      LAYOUT_BLIND_G_H, LAYOUT_BLIND_G, BASE_BBLIND, BASE_G0, BASE_H0, BASE_B, NUM_BASES)
+                      LAYOUT_BLIND_G_H, LAYOUT_BLIND_G, BASE_BBLIND, BASE_G0, BASE_H0, BASE_B, NUM_BASES, STREAM_CONTEXT,
+                      compile_circuit)
 
 __all__ = ["Context", "BbpError", "lib", "lib_path", "STATUS", "SIGNATURES", "record_size", "entropy_size",
-           "LAYOUT_BLIND_G_H", "LAYOUT_BLIND_G", "BASE_BBLIND", "BASE_G0", "BASE_H0", "BASE_B", "NUM_BASES"]
+           "LAYOUT_BLIND_G_H", "LAYOUT_BLIND_G", "BASE_BBLIND", "BASE_G0", "BASE_H0", "BASE_B", "NUM_BASES", "STREAM_CONTEXT", "compile_circuit"]

@@ -11,7 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _VARIANT = os.environ.get("BBP_LIB_VARIANT", "")
 lib_path = os.path.join(_HERE, "libbbp_hip.%s.so" % _VARIANT if _VARIANT else "libbbp_hip.so")
 
-STATUS = {0: "OK", 1: "VERIFY", 2: "GENS_LEN", 3: "FORMAT", 4: "BAD_ARG", 5: "DEVICE"}
+STATUS = {0: "OK", 1: "VERIFY", 2: "GENS_LEN", 3: "FORMAT", 4: "BAD_ARG", 5: "DEVICE", 6: "INTERNAL"}
+STREAM_CONTEXT = ctypes.c_void_p(-1).value  # BBP_STREAM_CONTEXT: the context's own stream; 0 / None-less handles are the caller's hipStream_t
 LAYOUT_BLIND_G_H, LAYOUT_BLIND_G = 0, 1
 BASE_BBLIND, BASE_G0, BASE_H0, BASE_B, NUM_BASES = 0, 1, 2049, 4097, 4098
 R1CS_PROOF_BYTES = 1121
@@ -38,6 +39,9 @@ SIGNATURES = {
     "bbp_prepare_bids_dev": (_i32, [_vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "bbp_verify_batch_aggregated": (_i32, [_vp, _u32, _u32, _vp, _vp, _u32, _vp]),
     "bbp_verify_batch_aggregated_dev": (_i32, [_vp, _u32, _u32, _vp, _vp, _vp, _u32, _vp, _vp]),
+    "bbp_set_batching": (_i32, [_vp, _u32, _u32]),
+    "bbp_batching_stats": (_i32, [_vp, ctypes.POINTER(_u64), ctypes.POINTER(_u64), ctypes.POINTER(_u32)]),
+    "bbp_debug_compile_circuit": (_i32, [_u32, ctypes.POINTER(_u32), ctypes.POINTER(_u32)]),
     "bbp_debug_challenges": (_i32, [_vp, _u32, _u32, _u32, _vp]),
     "bbp_ubench": (_i32, [_vp, _i32, _u32, _u32, ctypes.POINTER(ctypes.c_double)]),
     "bbp_set_profiling": (_i32, [_vp, _i32]),
@@ -74,6 +78,18 @@ def entropy_size(n):
 
 def _buf(b):
     return (ctypes.c_uint8 * len(b)).from_buffer_copy(bytes(b))
+
+
+def _stream(s):
+    """None -> the context's own stream (BBP_STREAM_CONTEXT); an int is a hipStream_t handle (0 = the legacy default stream)."""
+    return STREAM_CONTEXT if s is None else s
+
+
+def compile_circuit(n_items):
+    """Host-only synthesis of the blind-bid circuit for a list length (no device): (status, n_mul, n_cons)."""
+    a, b = ctypes.c_uint32(), ctypes.c_uint32()
+    rc = lib.bbp_debug_compile_circuit(n_items, ctypes.byref(a), ctypes.byref(b))
+    return rc, a.value, b.value
 
 
 class Context:
@@ -125,8 +141,8 @@ class Context:
         self._check(lib.bbp_msm_batch(self._h, B, n_terms, _buf(scalars), layout, out))
         return bytes(out)
 
-    def msm_batch_dev(self, B, n_terms, scalars_ptr, layout, out_ptr, stream=0):
-        self._check(lib.bbp_msm_batch_dev(self._h, B, n_terms, scalars_ptr, layout, out_ptr, stream))
+    def msm_batch_dev(self, B, n_terms, scalars_ptr, layout, out_ptr, stream=None):
+        self._check(lib.bbp_msm_batch_dev(self._h, B, n_terms, scalars_ptr, layout, out_ptr, _stream(stream)))
 
     def witness_batch(self, dks):
         B = len(dks) // 96
@@ -162,9 +178,9 @@ class Context:
         self._check(lib.bbp_verify_batch(self._h, B, N, _buf(inputs), status))
         return list(status)
 
-    def prepare_bids_dev(self, B, N, bids_ptr, lists_ptr, toggles_ptr, prove_in_ptr, verify_tail_ptr=None, stream=0):
+    def prepare_bids_dev(self, B, N, bids_ptr, lists_ptr, toggles_ptr, prove_in_ptr, verify_tail_ptr=None, stream=None):
         """Device-side caller pass: (d,k,seed) + bid list + toggle -> rows for prove_batch_dev / the tail of verify_batch_dev rows."""
-        self._check(lib.bbp_prepare_bids_dev(self._h, B, N, bids_ptr, lists_ptr, toggles_ptr, prove_in_ptr, verify_tail_ptr, stream))
+        self._check(lib.bbp_prepare_bids_dev(self._h, B, N, bids_ptr, lists_ptr, toggles_ptr, prove_in_ptr, verify_tail_ptr, _stream(stream)))
 
     def verify_batch_aggregated(self, B, N, inputs, group=0):
         """Statuses as verify_batch; proofs are checked in groups of `group` (0 = default 32) with one generator MSM per group,
@@ -174,16 +190,26 @@ class Context:
         self._check(lib.bbp_verify_batch_aggregated(self._h, B, N, _buf(inputs), status, group, ctypes.byref(nfb)))
         return list(status), nfb.value
 
-    def verify_batch_aggregated_dev(self, B, N, in_ptr, ent_ptr, status_ptr, group=0, stream=0):
+    def verify_batch_aggregated_dev(self, B, N, in_ptr, ent_ptr, status_ptr, group=0, stream=None):
         nfb = ctypes.c_uint32()
-        self._check(lib.bbp_verify_batch_aggregated_dev(self._h, B, N, in_ptr, ent_ptr, status_ptr, group, ctypes.byref(nfb), stream))
+        self._check(lib.bbp_verify_batch_aggregated_dev(self._h, B, N, in_ptr, ent_ptr, status_ptr, group, ctypes.byref(nfb), _stream(stream)))
         return nfb.value
 
-    def prove_batch_dev(self, B, N, in_ptr, ent_ptr, out_ptr, stream=0):
-        self._check(lib.bbp_prove_batch_dev(self._h, B, N, in_ptr, ent_ptr, out_ptr, stream))
+    def prove_batch_dev(self, B, N, in_ptr, ent_ptr, out_ptr, stream=None):
+        self._check(lib.bbp_prove_batch_dev(self._h, B, N, in_ptr, ent_ptr, out_ptr, _stream(stream)))
 
-    def verify_batch_dev(self, B, N, in_ptr, ent_ptr, status_ptr, stream=0):
-        self._check(lib.bbp_verify_batch_dev(self._h, B, N, in_ptr, ent_ptr, status_ptr, stream))
+    def verify_batch_dev(self, B, N, in_ptr, ent_ptr, status_ptr, stream=None):
+        self._check(lib.bbp_verify_batch_dev(self._h, B, N, in_ptr, ent_ptr, status_ptr, _stream(stream)))
+
+    def set_batching(self, window_us=0, max_batch=0):
+        """Micro-batching window / size bound of the call combiner (concurrent prove() / verify() callers share device batches)."""
+        self._check(lib.bbp_set_batching(self._h, window_us, max_batch))
+
+    def batching_stats(self):
+        """(combined device calls, requests they carried, largest batch) since the context was created."""
+        a, b, c = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint32()
+        self._check(lib.bbp_batching_stats(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return a.value, b.value, c.value
 
     def debug_challenges(self, B, N, proof):
         out = (ctypes.c_uint8 * (32 * 32))()

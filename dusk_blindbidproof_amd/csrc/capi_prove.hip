@@ -3,6 +3,7 @@
 #include <string.h>
 
 #include "batch.h"
+#include "submit.h"
 
 namespace bbp {
 int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* ent_dev, u8* out_dev, hipStream_t s);
@@ -103,46 +104,68 @@ static bool os_random(uint8_t* buf, size_t n) {
 
 using namespace bbp;
 
+namespace bbp {
+std::string& tls_error() {
+    static thread_local std::string e;
+    return e;
+}
+int32_t fault_injected(const char* site) {
+    const char* e = getenv("BBP_FAULT_INJECT");
+    if (e && strcmp(e, site) == 0) throw std::runtime_error(std::string("injected fault at ") + site);
+    if (e && strcmp(e, "alloc") == 0 && strcmp(site, "prove_batch") == 0) throw std::bad_alloc();
+    return 0;
+}
+// entry points without a context to lock still keep every exception on this side of the boundary
+template <class F>
+static int32_t no_throw(F&& body) noexcept {
+    try {
+        return body();
+    } catch (const std::invalid_argument& e) {
+        try { tls_error() = std::string("invalid argument: ") + e.what(); } catch (...) {}
+        return BBP_ERR_BAD_ARG;
+    } catch (const std::exception& e) {
+        try { tls_error() = std::string("internal error: ") + e.what(); } catch (...) {}
+        return BBP_ERR_INTERNAL;
+    } catch (...) {
+        return BBP_ERR_INTERNAL;
+    }
+}
+}  // namespace bbp
+
 extern "C" uint32_t bbp_proof_record_size(uint32_t N) { return BBP_R1CS_PROOF_BYTES + 32u * (4u + N); }
 extern "C" uint32_t bbp_entropy_size(uint32_t N) { return 32u * (4u + N) + 32u; }
+
+extern "C" int32_t bbp_debug_compile_circuit(uint32_t N, uint32_t* n_mul, uint32_t* n_cons) {
+    return no_throw([&]() -> int32_t {
+        if (N > BBP_MAX_ITEMS) return BBP_ERR_GENS_LEN;
+        fault_injected("compile");
+        const circuit::Compiled c = circuit::compile(N);  // throws std::invalid_argument for N == 0 (src/gadgets.rs:103 panics)
+        if (n_mul) *n_mul = c.n_mul;
+        if (n_cons) *n_cons = c.n_cons;
+        return BBP_OK;
+    });
+}
 
 extern "C" int32_t bbp_witness_batch(bbp_ctx* ctx, uint32_t B, const uint8_t* dks, uint8_t* out) {
     if (!ctx || !dks || !out) return BBP_ERR_BAD_ARG;
     if (B == 0) return BBP_OK;
-    BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int32_t rc;
-    if ((rc = dev_reserve(ctx, ctx->io_in, 96 * (size_t)B)) || (rc = dev_reserve(ctx, ctx->io_out, 192 * (size_t)B))) return rc;
-    BBP_HIP_TRY(ctx, hipMemcpyAsync(ctx->io_in.p, dks, 96 * (size_t)B, hipMemcpyHostToDevice, ctx->stream));
-    {
-        ScopedEvent ev(ctx, TAG_WITNESS, ctx->stream);
-        hipLaunchKernelGGL(k_witness_native, dim3((B + 63) / 64), dim3(64), 0, ctx->stream, B, (const u8*)ctx->io_in.p, ctx->mimc_c,
-                           (u8*)ctx->io_out.p);
-        BBP_HIP_TRY(ctx, hipGetLastError());
-    }
-    BBP_HIP_TRY(ctx, hipMemcpyAsync(out, ctx->io_out.p, 192 * (size_t)B, hipMemcpyDeviceToHost, ctx->stream));
-    BBP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return BBP_OK;
-}
-
-static int32_t check_n(bbp_ctx* ctx, uint32_t N);
-extern "C" int32_t bbp_prepare_bids_dev(bbp_ctx* ctx, uint32_t B, uint32_t N, const void* bids_dev, const void* lists_dev,
-                                        const void* toggles_dev, void* prove_in_dev, void* verify_tail_dev, void* stream) {
-    if (!ctx || !bids_dev || !lists_dev || !toggles_dev || !prove_in_dev) return BBP_ERR_BAD_ARG;
-    int32_t rc = check_n(ctx, N);
-    if (rc) return rc;
-    if (B == 0) return BBP_OK;
-    BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-    {
-        ScopedEvent ev(ctx, TAG_WITNESS, s);
-        hipLaunchKernelGGL(k_prepare_bids, dim3((B + 63) / 64), dim3(64), 0, s, B, N, (const u8*)bids_dev, (const u8*)lists_dev,
-                           (const u64*)toggles_dev, ctx->mimc_c, (u32*)prove_in_dev, (u32*)verify_tail_dev);
-        BBP_HIP_TRY(ctx, hipGetLastError());
-    }
-    // the prover's opening stage does not wait for the caller's stream (bbp.h); it does wait for this event
-    BBP_HIP_TRY(ctx, hipEventRecord(ctx->ev_prep, s));
-    ctx->ev_prep_valid = true;
-    return BBP_OK;
+    return api_guard(ctx, [&]() -> int32_t {
+        BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+        int32_t rc;
+        if ((rc = dev_reserve(ctx, ctx->io_in, 96 * (size_t)B)) || (rc = dev_reserve(ctx, ctx->io_out, 192 * (size_t)B))) return rc;
+        StreamGuard guard(ctx, ctx->stream);  // io_in / io_out are shared with the other host-pointer entry points
+        if ((rc = guard.enter())) return rc;
+        BBP_HIP_TRY(ctx, hipMemcpyAsync(ctx->io_in.p, dks, 96 * (size_t)B, hipMemcpyHostToDevice, ctx->stream));
+        {
+            ScopedEvent ev(ctx, TAG_WITNESS, ctx->stream);
+            hipLaunchKernelGGL(k_witness_native, dim3((B + 63) / 64), dim3(64), 0, ctx->stream, B, (const u8*)ctx->io_in.p, ctx->mimc_c,
+                               (u8*)ctx->io_out.p);
+            BBP_HIP_TRY(ctx, hipGetLastError());
+        }
+        BBP_HIP_TRY(ctx, hipMemcpyAsync(out, ctx->io_out.p, 192 * (size_t)B, hipMemcpyDeviceToHost, ctx->stream));
+        BBP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return BBP_OK;
+    });
 }
 
 static int32_t check_n(bbp_ctx* ctx, uint32_t N) {
@@ -157,12 +180,35 @@ static int32_t check_n(bbp_ctx* ctx, uint32_t N) {
     return BBP_OK;
 }
 
-extern "C" int32_t bbp_prove_batch(bbp_ctx* ctx, uint32_t B, uint32_t N, const uint8_t* in, const uint8_t* entropy, uint8_t* out,
-                                   int32_t* status) {
-    if (!ctx || !in || !out || !status) return BBP_ERR_BAD_ARG;
+extern "C" int32_t bbp_prepare_bids_dev(bbp_ctx* ctx, uint32_t B, uint32_t N, const void* bids_dev, const void* lists_dev,
+                                        const void* toggles_dev, void* prove_in_dev, void* verify_tail_dev, void* stream) {
+    if (!ctx || !bids_dev || !lists_dev || !toggles_dev || !prove_in_dev) return BBP_ERR_BAD_ARG;
+    return api_guard(ctx, [&]() -> int32_t {
+        int32_t rc = check_n(ctx, N);
+        if (rc) return rc;
+        if (B == 0) return BBP_OK;
+        BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+        hipStream_t s = pick_stream(ctx, stream);
+        {
+            ScopedEvent ev(ctx, TAG_WITNESS, s);
+            hipLaunchKernelGGL(k_prepare_bids, dim3((B + 63) / 64), dim3(64), 0, s, B, N, (const u8*)bids_dev, (const u8*)lists_dev,
+                               (const u64*)toggles_dev, ctx->mimc_c, (u32*)prove_in_dev, (u32*)verify_tail_dev);
+            BBP_HIP_TRY(ctx, hipGetLastError());
+        }
+        // the prover's opening stage does not wait for the caller's stream (bbp.h); it does wait for this event
+        BBP_HIP_TRY(ctx, hipEventRecord(ctx->ev_prep, s));
+        ctx->ev_prep_valid = true;
+        return BBP_OK;
+    });
+}
+
+// body of bbp_prove_batch; the context lock is held by the caller
+static int32_t prove_batch_host(bbp_ctx* ctx, uint32_t B, uint32_t N, const uint8_t* in, const uint8_t* entropy, uint8_t* out,
+                                int32_t* status) {
     int32_t rc = check_n(ctx, N);
     if (rc) return rc;
     if (B == 0) return BBP_OK;
+    fault_injected("prove_batch");
     BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t in_stride = 7 * 32 + (size_t)N * 32 + 8, ent_stride = bbp_entropy_size(N), out_stride = bbp_proof_record_size(N);
     // host-side argument screening (the reference's typed API cannot express these states: SURVEY.md 8b)
@@ -209,9 +255,13 @@ extern "C" int32_t bbp_prove_batch(bbp_ctx* ctx, uint32_t B, uint32_t N, const u
     if ((rc = dev_reserve(ctx, ctx->io_in, in_stride * B)) || (rc = dev_reserve(ctx, ctx->io_ent, ent_stride * B)) ||
         (rc = dev_reserve(ctx, ctx->io_out, out_stride * B)))
         return rc;
-    BBP_HIP_TRY(ctx, hipMemcpyAsync(ctx->io_in.p, src, in_stride * B, hipMemcpyHostToDevice, ctx->stream));
-    BBP_HIP_TRY(ctx, hipMemcpyAsync(ctx->io_ent.p, entropy, ent_stride * B, hipMemcpyHostToDevice, ctx->stream));
-    BBP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors may go out of scope
+    {
+        StreamGuard guard(ctx, ctx->stream);  // io_* may still be read by an earlier call issued on another stream
+        if ((rc = guard.enter())) return rc;
+        BBP_HIP_TRY(ctx, hipMemcpyAsync(ctx->io_in.p, src, in_stride * B, hipMemcpyHostToDevice, ctx->stream));
+        BBP_HIP_TRY(ctx, hipMemcpyAsync(ctx->io_ent.p, entropy, ent_stride * B, hipMemcpyHostToDevice, ctx->stream));
+        BBP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors may go out of scope
+    }
     // Very large host batches go through the engine in equal chunks of at most host_chunk_prove proofs so that scratch stays
     // bounded (~1.3 MB per proof of the largest call, three buffers); consecutive calls pipeline -- chunk k+1's opening stage
     // under chunk k's MSMs.  One 16384-proof call was measured 5 % faster than four of 4096, hence the large default.
@@ -229,35 +279,58 @@ extern "C" int32_t bbp_prove_batch(bbp_ctx* ctx, uint32_t B, uint32_t N, const u
     return BBP_OK;
 }
 
+extern "C" int32_t bbp_prove_batch(bbp_ctx* ctx, uint32_t B, uint32_t N, const uint8_t* in, const uint8_t* entropy, uint8_t* out,
+                                   int32_t* status) {
+    if (!ctx || !in || !out || !status) return BBP_ERR_BAD_ARG;
+    return api_guard(ctx, [&]() -> int32_t { return prove_batch_host(ctx, B, N, in, entropy, out, status); });
+}
+
 extern "C" int32_t bbp_prove_batch_dev(bbp_ctx* ctx, uint32_t B, uint32_t N, const void* in_dev, const void* entropy_dev, void* out_dev,
                                        void* stream) {
     if (!ctx || !in_dev || !entropy_dev || !out_dev) return BBP_ERR_BAD_ARG;
-    int32_t rc = check_n(ctx, N);
-    if (rc) return rc;
-    if (B == 0) return BBP_OK;
-    BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    return prove_batch_dev(ctx, B, N, (const u8*)in_dev, (const u8*)entropy_dev, (u8*)out_dev, stream ? (hipStream_t)stream : ctx->stream);
+    return api_guard(ctx, [&]() -> int32_t {
+        int32_t rc = check_n(ctx, N);
+        if (rc) return rc;
+        if (B == 0) return BBP_OK;
+        BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+        return prove_batch_dev(ctx, B, N, (const u8*)in_dev, (const u8*)entropy_dev, (u8*)out_dev, pick_stream(ctx, stream));
+    });
+}
+
+// what the call combiner runs for a group of concurrent bbp_prove callers (submit.cpp)
+int32_t bbp::prove_batch_locked(bbp_ctx* ctx, uint32_t B, uint32_t N, const uint8_t* in, const uint8_t* entropy, uint8_t* out,
+                                int32_t* status, std::string* err) {
+    const int32_t rc = api_guard(ctx, [&]() -> int32_t { return prove_batch_host(ctx, B, N, in, entropy, out, status); });
+    if (rc && err) *err = tls_error();
+    return rc;
 }
 
 extern "C" int32_t bbp_prove(bbp_ctx* ctx, const uint8_t scalars7[7 * 32], const uint8_t* pub_list, uint32_t N, uint64_t toggle,
                              const uint8_t* entropy, uint8_t* proof_out, uint32_t* proof_len) {
     if (!ctx || !scalars7 || !proof_out) return BBP_ERR_BAD_ARG;
-    int32_t rc = check_n(ctx, N);
+    int32_t rc = api_guard(ctx, [&]() -> int32_t { return check_n(ctx, N); });
     if (rc) return rc;
     if (!pub_list) return BBP_ERR_BAD_ARG;
-    std::vector<uint8_t> in(7 * 32 + (size_t)N * 32 + 8);
-    memcpy(&in[0], scalars7, 7 * 32);
-    memcpy(&in[7 * 32], pub_list, (size_t)N * 32);
-    memcpy(&in[7 * 32 + (size_t)N * 32], &toggle, 8);
-    int32_t st = BBP_OK;
-    rc = bbp_prove_batch(ctx, 1, N, in.data(), entropy, proof_out, &st);
-    if (rc) return rc;
-    if (st != BBP_OK) {
-        ctx->err = st == BBP_ERR_BAD_ARG ? "toggle >= N" : "non-canonical scalar input";
-        return st;
-    }
-    if (proof_len) *proof_len = BBP_R1CS_PROOF_BYTES;
-    return BBP_OK;
+    return no_throw([&]() -> int32_t {
+        std::vector<uint8_t> in(7 * 32 + (size_t)N * 32 + 8);
+        memcpy(&in[0], scalars7, 7 * 32);
+        memcpy(&in[7 * 32], pub_list, (size_t)N * 32);
+        memcpy(&in[7 * 32 + (size_t)N * 32], &toggle, 8);
+        Request r;
+        r.kind = 0;
+        r.N = N;
+        r.in = in.data();
+        r.in_len = in.size();
+        r.entropy = entropy;
+        r.out = proof_out;
+        const int32_t st = static_cast<Combiner*>(ctx->combiner)->submit(ctx, r);
+        if (st != BBP_OK) {
+            tls_error() = !r.err.empty() ? r.err : st == BBP_ERR_BAD_ARG ? "toggle >= N" : "non-canonical scalar input";
+            return st;
+        }
+        if (proof_len) *proof_len = BBP_R1CS_PROOF_BYTES;
+        return BBP_OK;
+    });
 }
 
 // rec_ver 0: compact 1121-byte proofs; 1: the 2-phase 1217-byte R1CSProof layout (both parse in the reference)
@@ -274,9 +347,13 @@ static int32_t verify_batch_host(bbp_ctx* ctx, uint32_t B, uint32_t N, uint32_t 
     if ((rc = dev_reserve(ctx, ctx->io_in, stride * B)) || (rc = dev_reserve(ctx, ctx->io_ent, 32 * (size_t)B)) ||
         (rc = dev_reserve(ctx, ctx->io_out, 4 * (size_t)B)))
         return rc;
-    BBP_HIP_TRY(ctx, hipMemcpyAsync(ctx->io_in.p, in, stride * B, hipMemcpyHostToDevice, ctx->stream));
-    BBP_HIP_TRY(ctx, hipMemcpyAsync(ctx->io_ent.p, ent.data(), ent.size(), hipMemcpyHostToDevice, ctx->stream));
-    BBP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    {
+        StreamGuard guard(ctx, ctx->stream);
+        if ((rc = guard.enter())) return rc;
+        BBP_HIP_TRY(ctx, hipMemcpyAsync(ctx->io_in.p, in, stride * B, hipMemcpyHostToDevice, ctx->stream));
+        BBP_HIP_TRY(ctx, hipMemcpyAsync(ctx->io_ent.p, ent.data(), ent.size(), hipMemcpyHostToDevice, ctx->stream));
+        BBP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
     const uint32_t n_chunks = (B + host_chunk_verify() - 1) / host_chunk_verify(), chunk = (B + n_chunks - 1) / n_chunks;
     for (uint32_t first = 0; first < B; first += chunk) {  // bounded scratch for any B (see bbp_prove_batch)
         const uint32_t nb = B - first < chunk ? B - first : chunk;
@@ -294,51 +371,65 @@ static int32_t verify_batch_host(bbp_ctx* ctx, uint32_t B, uint32_t N, uint32_t 
     return BBP_OK;
 }
 
+int32_t bbp::verify_batch_locked(bbp_ctx* ctx, uint32_t B, uint32_t N, uint32_t rec_ver, const uint8_t* in, int32_t* status,
+                                 std::string* err) {
+    const int32_t rc = api_guard(ctx, [&]() -> int32_t { return verify_batch_host(ctx, B, N, rec_ver, in, status); });
+    if (rc && err) *err = tls_error();
+    return rc;
+}
+
 extern "C" int32_t bbp_verify_batch(bbp_ctx* ctx, uint32_t B, uint32_t N, const uint8_t* in, int32_t* status) {
     if (!ctx || !in || !status) return BBP_ERR_BAD_ARG;
-    int32_t rc = check_n(ctx, N);
-    if (rc) return rc;
-    if (B == 0) return BBP_OK;
-    return verify_batch_host(ctx, B, N, 0, in, status);
+    return api_guard(ctx, [&]() -> int32_t {
+        int32_t rc = check_n(ctx, N);
+        if (rc) return rc;
+        if (B == 0) return BBP_OK;
+        return verify_batch_host(ctx, B, N, 0, in, status);
+    });
 }
 
 extern "C" int32_t bbp_verify_batch_dev(bbp_ctx* ctx, uint32_t B, uint32_t N, const void* in_dev, const void* entropy_dev,
                                         void* status_dev, void* stream) {
     if (!ctx || !in_dev || !entropy_dev || !status_dev) return BBP_ERR_BAD_ARG;
-    int32_t rc = check_n(ctx, N);
-    if (rc) return rc;
-    if (B == 0) return BBP_OK;
-    BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    return verify_batch_dev(ctx, B, N, (const u8*)in_dev, (const u8*)entropy_dev, (int32_t*)status_dev,
-                            stream ? (hipStream_t)stream : ctx->stream);
+    return api_guard(ctx, [&]() -> int32_t {
+        int32_t rc = check_n(ctx, N);
+        if (rc) return rc;
+        if (B == 0) return BBP_OK;
+        BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+        return verify_batch_dev(ctx, B, N, (const u8*)in_dev, (const u8*)entropy_dev, (int32_t*)status_dev, pick_stream(ctx, stream));
+    });
 }
 
 extern "C" int32_t bbp_verify_batch_aggregated(bbp_ctx* ctx, uint32_t B, uint32_t N, const uint8_t* in, int32_t* status, uint32_t group,
                                                uint32_t* n_fallback) {
     if (n_fallback) *n_fallback = 0;
     if (!ctx || !in || !status) return BBP_ERR_BAD_ARG;
-    int32_t rc = check_n(ctx, N);
-    if (rc) return rc;
-    if (B == 0) return BBP_OK;
-    return verify_batch_host(ctx, B, N, 0, in, status, group ? group : BBP_AGG_GROUP_DEFAULT, n_fallback);
+    return api_guard(ctx, [&]() -> int32_t {
+        int32_t rc = check_n(ctx, N);
+        if (rc) return rc;
+        if (B == 0) return BBP_OK;
+        return verify_batch_host(ctx, B, N, 0, in, status, group ? group : BBP_AGG_GROUP_DEFAULT, n_fallback);
+    });
 }
 
 extern "C" int32_t bbp_verify_batch_aggregated_dev(bbp_ctx* ctx, uint32_t B, uint32_t N, const void* in_dev, const void* entropy_dev,
                                                    void* status_dev, uint32_t group, uint32_t* n_fallback, void* stream) {
     if (n_fallback) *n_fallback = 0;
     if (!ctx || !in_dev || !entropy_dev || !status_dev) return BBP_ERR_BAD_ARG;
-    int32_t rc = check_n(ctx, N);
-    if (rc) return rc;
-    if (B == 0) return BBP_OK;
-    BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    return verify_batch_agg_dev(ctx, B, N, group ? group : BBP_AGG_GROUP_DEFAULT, (const u8*)in_dev, (const u8*)entropy_dev,
-                                (int32_t*)status_dev, stream ? (hipStream_t)stream : ctx->stream, n_fallback);
+    return api_guard(ctx, [&]() -> int32_t {
+        int32_t rc = check_n(ctx, N);
+        if (rc) return rc;
+        if (B == 0) return BBP_OK;
+        BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+        return verify_batch_agg_dev(ctx, B, N, group ? group : BBP_AGG_GROUP_DEFAULT, (const u8*)in_dev, (const u8*)entropy_dev,
+                                    (int32_t*)status_dev, pick_stream(ctx, stream), n_fallback);
+    });
 }
 
 extern "C" int32_t bbp_verify(bbp_ctx* ctx, const uint8_t* record, uint32_t record_len, const uint8_t score[32], const uint8_t z_img[32],
                               const uint8_t seed[32], const uint8_t* pub_list, uint32_t N) {
     if (!ctx || !record || !score || !z_img || !seed) return BBP_ERR_BAD_ARG;
-    int32_t rc = check_n(ctx, N);
+    int32_t rc = api_guard(ctx, [&]() -> int32_t { return check_n(ctx, N); });
     if (rc) return rc;
     if (!pub_list) return BBP_ERR_BAD_ARG;
     // Structural parse exactly as R1CSProof::from_bytes / InnerProductProof::from_bytes order their checks:
@@ -364,49 +455,84 @@ extern "C" int32_t bbp_verify(bbp_ctx* ctx, const uint8_t* record, uint32_t reco
     const uint32_t lg_n = (ipp_el - 2u) / 2u;
     if (lg_n >= 32u) return BBP_ERR_FORMAT;
     if (!canonical(nel - 2u) || !canonical(nel - 1u)) return BBP_ERR_FORMAT;  // a, b
+    // score, z_img, seed reach Verify::new as serde-deserialised Scalars (verify.rs:100-104): canonical encodings only
+    for (const uint8_t* pub : {score, z_img, seed}) {
+        u32 w[8];
+        memcpy(w, pub, 32);
+        if (!sc_is_canonical(w)) return BBP_ERR_FORMAT;
+    }
     if (lg_n != 11u) return BBP_ERR_VERIFY;  // padded_n = 2048 != 2^lg_n
-    std::vector<uint8_t> in((size_t)record_len + 96 + (size_t)N * 32);
-    memcpy(&in[0], record, record_len);
-    memcpy(&in[record_len], score, 32);
-    memcpy(&in[record_len + 32], z_img, 32);
-    memcpy(&in[record_len + 64], seed, 32);
-    memcpy(&in[record_len + 96], pub_list, (size_t)N * 32);
-    int32_t st = BBP_ERR_DEVICE;
-    rc = verify_batch_host(ctx, 1, N, ver, in.data(), &st);
-    if (rc) return rc;
-    return st;
+    return no_throw([&]() -> int32_t {
+        std::vector<uint8_t> in((size_t)record_len + 96 + (size_t)N * 32);
+        memcpy(&in[0], record, record_len);
+        memcpy(&in[record_len], score, 32);
+        memcpy(&in[record_len + 32], z_img, 32);
+        memcpy(&in[record_len + 64], seed, 32);
+        memcpy(&in[record_len + 96], pub_list, (size_t)N * 32);
+        Request r;
+        r.kind = 1;
+        r.N = N;
+        r.rec_ver = ver;
+        r.in = in.data();
+        r.in_len = in.size();
+        const int32_t st = static_cast<Combiner*>(ctx->combiner)->submit(ctx, r);
+        if (st != BBP_OK && !r.err.empty()) tls_error() = r.err;
+        return st;
+    });
+}
+
+extern "C" int32_t bbp_set_batching(bbp_ctx* ctx, uint32_t window_us, uint32_t max_batch) {
+    if (!ctx || !ctx->combiner) return BBP_ERR_BAD_ARG;
+    return no_throw([&]() -> int32_t {
+        static_cast<Combiner*>(ctx->combiner)->configure(window_us, max_batch);
+        return BBP_OK;
+    });
+}
+
+extern "C" int32_t bbp_batching_stats(bbp_ctx* ctx, uint64_t* n_calls, uint64_t* n_requests, uint32_t* max_seen) {
+    if (!ctx || !ctx->combiner) return BBP_ERR_BAD_ARG;
+    return no_throw([&]() -> int32_t {
+        static_cast<Combiner*>(ctx->combiner)->stats(n_calls, n_requests, max_seen);
+        return BBP_OK;
+    });
 }
 
 extern "C" int32_t bbp_debug_challenges(bbp_ctx* ctx, uint32_t B, uint32_t N, uint32_t proof, uint8_t* out32x32) {
     if (!ctx || !out32x32 || proof >= B) return BBP_ERR_BAD_ARG;
-    BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    BBP_HIP_TRY(ctx, hipDeviceSynchronize());
-    return debug_read_misc(ctx, B, N, proof, out32x32);
+    return api_guard(ctx, [&]() -> int32_t {
+        BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+        BBP_HIP_TRY(ctx, hipDeviceSynchronize());
+        return debug_read_misc(ctx, B, N, proof, out32x32);
+    });
 }
 
 extern "C" int32_t bbp_set_profiling(bbp_ctx* ctx, int32_t on) {
     if (!ctx) return BBP_ERR_BAD_ARG;
-    ctx->profile = on != 0;
-    return BBP_OK;
+    return api_guard(ctx, [&]() -> int32_t {
+        ctx->profile = on != 0;
+        return BBP_OK;
+    });
 }
 
 // Drains the recorded events: out[2i] = kernel tag, out[2i+1] = microseconds. Synchronises the device.
 extern "C" int32_t bbp_last_timings(bbp_ctx* ctx, float* out, uint32_t cap, uint32_t* n) {
     if (!ctx || !n) return BBP_ERR_BAD_ARG;
-    BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    BBP_HIP_TRY(ctx, hipDeviceSynchronize());
-    uint32_t k = 0;
-    for (auto& e : ctx->events) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess && out && 2 * k + 1 < cap) {
-            out[2 * k] = (float)e.tag;
-            out[2 * k + 1] = ms * 1000.f;
-            k++;
+    return api_guard(ctx, [&]() -> int32_t {
+        BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+        BBP_HIP_TRY(ctx, hipDeviceSynchronize());
+        uint32_t k = 0;
+        for (auto& e : ctx->events) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess && out && 2 * k + 1 < cap) {
+                out[2 * k] = (float)e.tag;
+                out[2 * k + 1] = ms * 1000.f;
+                k++;
+            }
+            (void)hipEventDestroy(e.a);
+            (void)hipEventDestroy(e.b);
         }
-        (void)hipEventDestroy(e.a);
-        (void)hipEventDestroy(e.b);
-    }
-    ctx->events.clear();
-    *n = 2 * k;
-    return BBP_OK;
+        ctx->events.clear();
+        *n = 2 * k;
+        return BBP_OK;
+    });
 }

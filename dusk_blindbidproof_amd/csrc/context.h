@@ -4,6 +4,9 @@
 #include <stdint.h>
 
 #include <map>
+#include <mutex>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -55,6 +58,12 @@ struct DevBuf {
 }  // namespace bbp
 
 struct bbp_ctx {
+    // One lock per context: every extern "C" entry point that touches the context holds it for the whole call (api_guard below), so
+    // the reference's per-connection worker threads (src/main.rs:55, src/futures/main.rs:46-56) may share ONE context.  Recursive:
+    // bbp_prove -> bbp_prove_batch, bbp_msm_batch -> bbp_msm_batch_dev nest.  Concurrent single-proof callers do not queue on this
+    // lock one by one: submit.hip coalesces them into one batch call (group commit).
+    std::recursive_mutex mu;
+    void* combiner = nullptr;  // bbp::Combiner* (submit.hip): coalesces concurrent bbp_prove / bbp_verify calls into batch calls
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;            // opening stage of the prover pipeline (prover.hip)
@@ -101,6 +110,7 @@ struct bbp_ctx {
     void *agg_vs = nullptr, *agg_varsum = nullptr;  // weighted generator scalars [B][4098] / per-proof variable-base sums of that pass
     int32_t* agg_gstatus = nullptr;  // per-group verdicts of the last aggregated verification (inside agg)
     std::map<uint32_t, void*> circuits;  // N -> CircuitDev* (compiled blind-bid circuit tables on the device)
+    std::map<uint64_t, bbp::u32*> layout_idx;  // (layout << 32 | n_terms) -> device base-index list of bbp_msm_batch (capi_msm.hip)
     std::vector<float> timings;
     // optional per-kernel HIP-event timing (bbp_set_profiling): (tag, start, stop) on the launch stream
     bool profile = false;
@@ -157,15 +167,66 @@ struct ScopedEvent {  // records start now, stop at scope exit, when profiling i
 // see prover.hip "serial_lds_bytes": kernels that must not share a CU with the long-lived serial waves ask for a few bytes of LDS
 inline unsigned lds_token(const bbp_ctx* ctx) { return ctx->serial_lds >= 160 * 1024 ? 64u : 0u; }
 
-inline int32_t stream_guard_enter(bbp_ctx* ctx, hipStream_t s) {
-    if (ctx->ev_last_valid && ctx->last_stream != s) BBP_HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_last, 0));
-    return BBP_OK;
-}
-inline int32_t stream_guard_leave(bbp_ctx* ctx, hipStream_t s) {
-    BBP_HIP_TRY(ctx, hipEventRecord(ctx->ev_last, s));
-    ctx->ev_last_valid = true;
-    ctx->last_stream = s;
-    return BBP_OK;
+// Calls on one context share scratch: a call issued on a different caller stream than the previous one is ordered behind it.
+// RAII so that every exit path -- error returns included -- leaves ev_last recorded on the stream that may have work queued.
+struct StreamGuard {
+    bbp_ctx* ctx;
+    hipStream_t s;
+    bool entered = false;
+    StreamGuard(bbp_ctx* c, hipStream_t st) : ctx(c), s(st) {}
+    int32_t enter() {
+        if (ctx->ev_last_valid && ctx->last_stream != s) BBP_HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_last, 0));
+        entered = true;
+        return BBP_OK;
+    }
+    ~StreamGuard() {
+        if (!entered) return;
+        if (hipEventRecord(ctx->ev_last, s) == hipSuccess) {
+            ctx->ev_last_valid = true;
+            ctx->last_stream = s;
+        }
+    }
+};
+
+// `stream` argument of the _dev entry points: BBP_STREAM_CONTEXT selects the context's own stream, anything else -- NULL, the
+// legacy default stream, included -- is the caller's hipStream_t and is honoured as such (include/bbp.h)
+inline hipStream_t pick_stream(bbp_ctx* ctx, void* stream) { return stream == BBP_STREAM_CONTEXT ? ctx->stream : (hipStream_t)stream; }
+
+// ---- the extern "C" barrier: lock + no exception ever crosses the boundary (include/bbp.h promises both) ---------------------
+// bbp_last_error reports per calling thread: a failing call copies the context's message into a thread-local slot under the lock.
+std::string& tls_error();
+int32_t fault_injected(const char* site);  // BBP_FAULT_INJECT=<site>: throw at that site (tests/test_capi_symbols.py)
+
+template <class F>
+int32_t api_guard(bbp_ctx* ctx, F&& body) noexcept {
+    int32_t rc;
+    try {
+        std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+        try {
+            rc = body();
+        } catch (const std::invalid_argument& e) {
+            ctx->err = std::string("invalid argument: ") + e.what();
+            rc = BBP_ERR_BAD_ARG;
+        } catch (const std::bad_alloc&) {
+            ctx->err = "host allocation failed";
+            rc = BBP_ERR_INTERNAL;
+        } catch (const std::exception& e) {
+            ctx->err = std::string("internal error: ") + e.what();
+            rc = BBP_ERR_INTERNAL;
+        } catch (...) {
+            ctx->err = "internal error: unknown exception";
+            rc = BBP_ERR_INTERNAL;
+        }
+        if (rc != BBP_OK) {
+            try {
+                tls_error() = ctx->err;
+            } catch (...) {
+            }
+        }
+    } catch (...) {  // the lock itself (std::system_error)
+        rc = BBP_ERR_INTERNAL;
+    }
+    return rc;
 }
 
 // msm.hip

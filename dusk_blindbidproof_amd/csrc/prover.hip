@@ -110,12 +110,13 @@ __global__ void k_witness_head(u32 B, u32 n_items, u32 n_cst, const u8* __restri
     st_sc(&cst[circuit::CST_Q], s7[4]);
     for (u32 i = 0; i < n_items; i++) st_sc(&cst[circuit::CST_ITEM0 + i], sc_from_bits(in + 56 + 8 * i));  // bid.rs:27
     sc* v = v_all + (size_t)p * m;
-    const u32 toggle = in[56 + 8 * n_items];
+    // `x as u64 == toggle` (proof.rs:63): the whole u64 is compared -- toggle = 2^32 + 3 sets no bit
+    const u64 toggle = (u64)in[56 + 8 * n_items] | ((u64)in[56 + 8 * n_items + 1] << 32);
     st_sc(&v[0], s7[0]);
     st_sc(&v[1], s7[1]);
     st_sc(&v[2], s7[2]);  // y: committed but never wired into the gadget (proof.rs:55, 76-78)
     st_sc(&v[3], s7[3]);
-    for (u32 i = 0; i < n_items; i++) st_sc(&v[4 + i], i == toggle ? sc_one() : sc_zero());
+    for (u32 i = 0; i < n_items; i++) st_sc(&v[4 + i], (u64)i == toggle ? sc_one() : sc_zero());
 }
 
 // gates: one lane interprets the compiled gadget program of its proof (sequential MiMC chains) -> a_L, a_R, a_O
@@ -917,6 +918,7 @@ int32_t circuit_get(bbp_ctx* ctx, uint32_t n_items, const CircuitDev** out) {
         *out = static_cast<const CircuitDev*>(it->second);
         return BBP_OK;
     }
+    fault_injected("compile");
     circuit::Compiled c = circuit::compile(n_items);
     if (c.padded != 2048) {
         ctx->err = "circuit does not pad to 2048 multipliers";
@@ -1093,7 +1095,8 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
     // -- so it runs on the context's side stream into the batch buffer of this call's parity, while the caller's stream is
     // still busy with the MSM-heavy stage of the PREVIOUS call (other parity).  Events order: inputs (caller stream) ->
     // opening (side) -> heavy stage (caller stream); a buffer is reused only after its previous heavy stage has finished.
-    if ((rc = stream_guard_enter(ctx, s))) return rc;
+    StreamGuard guard(ctx, s);
+    if ((rc = guard.enter())) return rc;
     const u32 call = ctx->seq++;
     // Batches too small to fill three heavy slices are bound by the opening stage (its rng chain lasts ~40 ms whatever the
     // batch size), so their openings alternate between two streams and two of them are in flight at once; the heavy stage
@@ -1157,7 +1160,7 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
     BBP_HIP_TRY(ctx, hipEventRecord(ctx->ev_done[par], main_s));
     ctx->ev_done_valid[par] = true;
     ctx->last_par = par;
-    return stream_guard_leave(ctx, main_s);
+    return BBP_OK;  // ~StreamGuard records ev_last on the caller's stream
 }
 
 // pointers of `bd` advanced to proof `first` (every array is [proof][stride])

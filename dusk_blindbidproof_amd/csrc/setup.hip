@@ -11,6 +11,7 @@
 #include "context.h"
 #include "batch.h"
 #include "hosthash.h"
+#include "submit.h"
 
 namespace bbp {
 
@@ -101,9 +102,24 @@ static void mimc_constants_host(std::vector<uint8_t>& out) {
 
 using namespace bbp;
 
+static int32_t init_body(int32_t device, bbp_ctx** out);
+
 extern "C" int32_t bbp_init(int32_t device, bbp_ctx** out) {
     if (!out) return BBP_ERR_BAD_ARG;
     *out = nullptr;
+    try {
+        const int32_t rc = init_body(device, out);
+        if (rc != BBP_OK && *out) tls_error() = (*out)->err;
+        return rc;
+    } catch (const std::exception& e) {
+        if (*out) (*out)->err = std::string("bbp_init: ") + e.what();
+        return BBP_ERR_INTERNAL;
+    } catch (...) {
+        return BBP_ERR_INTERNAL;
+    }
+}
+
+static int32_t init_body(int32_t device, bbp_ctx** out) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
         fprintf(stderr, "bbp_init: no usable HIP device (count=%d, requested=%d); this library has no CPU path\n", ndev,
@@ -113,6 +129,8 @@ extern "C" int32_t bbp_init(int32_t device, bbp_ctx** out) {
     bbp_ctx* ctx = new bbp_ctx();
     ctx->device = device;
     *out = ctx;  // returned even on failure so bbp_last_error works; caller frees
+    ctx->combiner = new Combiner();
+    if (const char* e = getenv("BBP_BATCH_WINDOW_US")) static_cast<Combiner*>(ctx->combiner)->configure((uint32_t)atoi(e), 0);
     BBP_HIP_TRY(ctx, hipSetDevice(device));
     hipDeviceProp_t prop;
     BBP_HIP_TRY(ctx, hipGetDeviceProperties(&prop, device));
@@ -201,6 +219,11 @@ extern "C" void bbp_free(bbp_ctx* ctx) {
         delete c;
     }
     ctx->circuits.clear();
+    for (auto& kv : ctx->layout_idx)
+        if (kv.second) (void)hipFree(kv.second);
+    ctx->layout_idx.clear();
+    delete static_cast<Combiner*>(ctx->combiner);
+    ctx->combiner = nullptr;
     for (int i = 0; i < bbp_ctx::PROVE_BUFS; i++) {
         if (ctx->ev_entry[i]) (void)hipEventDestroy(ctx->ev_entry[i]);
         if (ctx->ev_open[i]) (void)hipEventDestroy(ctx->ev_open[i]);
@@ -221,23 +244,43 @@ extern "C" void bbp_free(bbp_ctx* ctx) {
     delete ctx;
 }
 
-extern "C" const char* bbp_last_error(const bbp_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+// per calling thread: the message of this thread's last failing call (api_guard copies it under the context lock); a thread
+// that has not failed yet sees the context's last message (single-threaded callers never notice the difference)
+extern "C" const char* bbp_last_error(const bbp_ctx* ctx) {
+    if (!ctx) return "null context";
+    try {
+        std::string& t = tls_error();
+        if (t.empty()) {
+            std::lock_guard<std::recursive_mutex> lk(const_cast<bbp_ctx*>(ctx)->mu);
+            t = ctx->err;
+        }
+        return t.c_str();
+    } catch (...) {
+        return "error text unavailable";
+    }
+}
 
 extern "C" int32_t bbp_get_generator(bbp_ctx* ctx, uint32_t index, uint8_t out32[32]) {
     if (!ctx || index >= BBP_NUM_BASES) return BBP_ERR_BAD_ARG;
-    BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int32_t rc = dev_reserve(ctx, ctx->enc, 32);
-    if (rc) return rc;
-    rc = encode_launch(ctx, 1, ctx->gens + index, (uint8_t*)ctx->enc.p, ctx->stream);
-    if (rc) return rc;
-    BBP_HIP_TRY(ctx, hipMemcpyAsync(out32, ctx->enc.p, 32, hipMemcpyDeviceToHost, ctx->stream));
-    BBP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return BBP_OK;
+    return api_guard(ctx, [&]() -> int32_t {
+        BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+        int32_t rc = dev_reserve(ctx, ctx->enc, 32);
+        if (rc) return rc;
+        StreamGuard guard(ctx, ctx->stream);
+        if ((rc = guard.enter())) return rc;
+        rc = encode_launch(ctx, 1, ctx->gens + index, (uint8_t*)ctx->enc.p, ctx->stream);
+        if (rc) return rc;
+        BBP_HIP_TRY(ctx, hipMemcpyAsync(out32, ctx->enc.p, 32, hipMemcpyDeviceToHost, ctx->stream));
+        BBP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return BBP_OK;
+    });
 }
 
 extern "C" int32_t bbp_get_mimc_constant(bbp_ctx* ctx, uint32_t i, uint8_t out32[32]) {
     if (!ctx || i >= BBP_MIMC_ROUNDS) return BBP_ERR_BAD_ARG;
-    BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    BBP_HIP_TRY(ctx, hipMemcpy(out32, ctx->mimc_c + i, 32, hipMemcpyDeviceToHost));  // read back from the device copy
-    return BBP_OK;
+    return api_guard(ctx, [&]() -> int32_t {
+        BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+        BBP_HIP_TRY(ctx, hipMemcpy(out32, ctx->mimc_c + i, 32, hipMemcpyDeviceToHost));  // read back from the device copy
+        return BBP_OK;
+    });
 }

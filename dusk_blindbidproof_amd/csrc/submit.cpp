@@ -1,0 +1,107 @@
+// Call combiner (see submit.h).  Host-only C++: no HIP in this file, so the same translation unit also builds into the stub
+// engine the CPU-tier server tests use (tests/stub_engine.cpp).
+#include "submit.h"
+
+#include <string.h>
+
+#include <chrono>
+
+namespace bbp {
+
+void Combiner::configure(uint32_t window_us, uint32_t max_batch) {
+    std::lock_guard<std::mutex> lk(mu_);
+    window_us_ = window_us;
+    max_batch_ = max_batch ? max_batch : 4096;
+}
+
+void Combiner::stats(uint64_t* n_calls, uint64_t* n_requests, uint32_t* max_seen) {
+    std::lock_guard<std::mutex> lk(mu_);
+    if (n_calls) *n_calls = n_calls_;
+    if (n_requests) *n_requests = n_requests_;
+    if (max_seen) *max_seen = max_seen_;
+}
+
+static bool same_class(const Request* a, const Request* b) {
+    return a->kind == b->kind && a->N == b->N && a->rec_ver == b->rec_ver && a->in_len == b->in_len && (a->entropy == nullptr) == (b->entropy == nullptr);
+}
+
+int32_t Combiner::submit(bbp_ctx* ctx, Request& r) {
+    std::unique_lock<std::mutex> lk(mu_);
+    q_.push_back(&r);
+    if (!leader_active_) {
+        leader_active_ = true;
+        r.lead = true;  // the queue was drained by the previous leader, so r is its head
+    } else {
+        cv_.notify_all();  // a leader sitting in its batching window counts arrivals
+    }
+    for (;;) {
+        cv_.wait(lk, [&] { return r.done || r.lead; });
+        if (r.done) return r.status;
+        // leader: r is the head of the queue.  Optional window: give concurrent callers a moment to join this batch.
+        if (window_us_) {
+            const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(window_us_);
+            while (q_.size() < max_batch_ && cv_.wait_until(lk, deadline) != std::cv_status::timeout) {
+            }
+        }
+        std::vector<Request*> batch;
+        for (auto it = q_.begin(); it != q_.end() && batch.size() < max_batch_;) {
+            if (same_class(*it, &r)) {
+                batch.push_back(*it);
+                it = q_.erase(it);
+            } else {
+                ++it;
+            }
+        }
+        lk.unlock();
+        run_batch(ctx, batch);  // r is in it
+        lk.lock();
+        n_calls_++;
+        n_requests_ += batch.size();
+        if (batch.size() > max_seen_) max_seen_ = (uint32_t)batch.size();
+        for (Request* b : batch) b->done = true;
+        r.lead = false;
+        if (q_.empty())
+            leader_active_ = false;
+        else
+            q_.front()->lead = true;  // hand over: nobody serves other callers for longer than one batch
+        cv_.notify_all();
+    }
+}
+
+void Combiner::run_batch(bbp_ctx* ctx, std::vector<Request*>& batch) {
+    const Request& h = *batch[0];
+    const uint32_t B = (uint32_t)batch.size();
+    int32_t rc;
+    std::string err;
+    std::vector<int32_t> status(B, 6);
+    try {
+        std::vector<uint8_t> in((size_t)B * h.in_len);
+        for (uint32_t i = 0; i < B; i++) memcpy(&in[(size_t)i * h.in_len], batch[i]->in, h.in_len);
+        if (h.kind == 0) {
+            const size_t ent_len = 32 * (4 + (size_t)h.N) + 32, rec_len = 1121 + 32 * (4 + (size_t)h.N);
+            std::vector<uint8_t> ent, out((size_t)B * rec_len);
+            if (h.entropy) {
+                ent.resize((size_t)B * ent_len);
+                for (uint32_t i = 0; i < B; i++) memcpy(&ent[(size_t)i * ent_len], batch[i]->entropy, ent_len);
+            }
+            rc = prove_batch_locked(ctx, B, h.N, in.data(), h.entropy ? ent.data() : nullptr, out.data(), status.data(), &err);
+            if (rc == 0)
+                for (uint32_t i = 0; i < B; i++)
+                    if (status[i] == 0) memcpy(batch[i]->out, &out[(size_t)i * rec_len], rec_len);
+        } else {
+            rc = verify_batch_locked(ctx, B, h.N, h.rec_ver, in.data(), status.data(), &err);
+        }
+    } catch (const std::bad_alloc&) {
+        rc = 6;
+        err = "host allocation failed";
+    } catch (...) {
+        rc = 6;
+        err = "internal error in combined call";
+    }
+    for (uint32_t i = 0; i < B; i++) {
+        batch[i]->status = rc ? rc : status[i];
+        if (rc) batch[i]->err = err;
+    }
+}
+
+}  // namespace bbp

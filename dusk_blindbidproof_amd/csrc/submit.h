@@ -1,0 +1,58 @@
+// Call combiner: turns concurrent single-proof callers into batch calls (group commit).
+//
+// The reference runs one Proof::prove / Verify::verify per dusk-uds worker thread (src/main.rs:55, src/futures/main.rs:46-56,
+// src/futures/prove.rs:21-26, verify.rs:21-26): N connections = N independent CPU proofs side by side.  On the GPU the unit of
+// efficiency is the batch, so bbp_prove / bbp_verify (and through them the UDS server under server/) hand their request to this
+// queue: the first caller to find the engine free becomes the leader, takes every queued request of its class (same kind, list
+// length, record layout, entropy mode), runs ONE bbp_prove_batch / bbp_verify_batch under the context lock and distributes the
+// results; requests that arrive while a batch is on the device form the next batch.  Leadership is handed to the head of the
+// queue after every batch, so no caller serves others for longer than one batch.
+#pragma once
+#include <stdint.h>
+
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <vector>
+
+struct bbp_ctx;
+
+namespace bbp {
+
+struct Request {
+    int kind = 0;                    // 0 = prove, 1 = verify
+    uint32_t N = 0;                  // bid-list length
+    uint32_t rec_ver = 0;            // verify: 0 = compact 1121-byte R1CSProof, 1 = two-phase 1217-byte layout
+    const uint8_t* in = nullptr;     // prove: scalars7 || pub_list || toggle ; verify: record || score || z_img || seed || pub_list
+    size_t in_len = 0;
+    const uint8_t* entropy = nullptr;  // prove only: bbp_entropy_size(N) bytes, or NULL = OS randomness
+    uint8_t* out = nullptr;          // prove only: bbp_proof_record_size(N) bytes
+    int32_t status = 6;              // BBP_ERR_INTERNAL until the batch has run
+    std::string err;
+    bool done = false, lead = false;
+};
+
+// what a combined call runs (capi_prove.hip); both take the context lock themselves
+int32_t prove_batch_locked(bbp_ctx* ctx, uint32_t B, uint32_t N, const uint8_t* in, const uint8_t* entropy, uint8_t* out, int32_t* status,
+                           std::string* err);
+int32_t verify_batch_locked(bbp_ctx* ctx, uint32_t B, uint32_t N, uint32_t rec_ver, const uint8_t* in, int32_t* status, std::string* err);
+
+class Combiner {
+  public:
+    int32_t submit(bbp_ctx* ctx, Request& r);
+    void configure(uint32_t window_us, uint32_t max_batch);
+    void stats(uint64_t* n_calls, uint64_t* n_requests, uint32_t* max_seen);
+
+  private:
+    void run_batch(bbp_ctx* ctx, std::vector<Request*>& batch);
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<Request*> q_;
+    bool leader_active_ = false;
+    uint32_t window_us_ = 0, max_batch_ = 4096;
+    uint64_t n_calls_ = 0, n_requests_ = 0;
+    uint32_t max_seen_ = 0;
+};
+
+}  // namespace bbp

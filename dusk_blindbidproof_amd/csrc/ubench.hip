@@ -96,7 +96,9 @@ using namespace bbp;
 // Runs `blocks` x 256 lanes x `iters` iterations; *ops_per_sec = operations/s (ops per iteration per lane: 4,2,2,1,2,1).
 extern "C" int32_t bbp_ubench(bbp_ctx* ctx, int32_t kind, uint32_t blocks, uint32_t iters, double* ops_per_sec) {
     if (!ctx || !ops_per_sec || kind < 0 || kind > 5 || blocks == 0) return BBP_ERR_BAD_ARG;
+    return api_guard(ctx, [&]() -> int32_t {
     BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    BBP_HIP_TRY(ctx, hipDeviceSynchronize());  // ctx->misc is the verifier's scratch: nothing of this context may still be using it
     int32_t rc = dev_reserve(ctx, ctx->misc, (size_t)blocks * 256 * 4);
     if (rc) return rc;
     hipEvent_t a, b;
@@ -122,4 +124,5 @@ extern "C" int32_t bbp_ubench(bbp_ctx* ctx, int32_t kind, uint32_t blocks, uint3
     const double per_iter[6] = {4, 2, 2, 1, 2, 1};
     *ops_per_sec = per_iter[kind] * (double)blocks * 256.0 * (double)iters / (ms * 1e-3);
     return BBP_OK;
+    });
 }

@@ -6,8 +6,16 @@
  *
  * Conventions: all scalars are 32-byte little-endian; points are 32-byte ristretto255 encodings; every buffer is
  * caller-owned host memory unless the name ends in `_dev`; functions return a bbp_status; nothing throws or
- * aborts across this boundary (the reference builds with panic='abort', Cargo.toml:29 -- see SURVEY.md 5).
+ * aborts across this boundary (the reference builds with panic='abort', Cargo.toml:29 -- see SURVEY.md 5): every entry point
+ * runs inside a try/catch barrier and turns a C++ exception into BBP_ERR_INTERNAL / BBP_ERR_BAD_ARG.
  * The library has NO CPU compute path: bbp_init fails with BBP_ERR_DEVICE when no gfx950 device is usable.
+ *
+ * Threading (SURVEY.md 8b "thread-safe after bbp_init"): the reference serves every connection on its own worker thread
+ * (src/main.rs:55, src/futures/main.rs:46-56, one Proof::prove / Verify::verify per thread).  ONE context may be shared by any
+ * number of host threads: each entry point takes the context's lock, and concurrent bbp_prove / bbp_verify calls are coalesced
+ * into batch calls on the device (group commit: whatever queued up while the previous batch ran goes out as the next batch), so
+ * N concurrent single proofs cost about one batch of N, not N times one.  bbp_last_error is per calling thread.
+ * bbp_free must not race with other calls on the same context.
  */
 #ifndef BBP_H
 #define BBP_H
@@ -25,7 +33,8 @@ typedef enum {
     BBP_ERR_GENS_LEN = 2,  /* R1CSError::InvalidGeneratorsLength: N > 202 needs > 2048 multipliers       */
     BBP_ERR_FORMAT = 3,    /* R1CSError::FormatError / Error::Io(InvalidData|UnexpectedEof) (error.rs)    */
     BBP_ERR_BAD_ARG = 4,   /* N == 0 or toggle >= N: the reference panics (src/gadgets.rs:103) or proves garbage */
-    BBP_ERR_DEVICE = 5     /* HIP failure / no device                                                     */
+    BBP_ERR_DEVICE = 5,    /* HIP failure / no device                                                     */
+    BBP_ERR_INTERNAL = 6   /* host-side failure (allocation, internal invariant, any C++ exception): reported, never thrown */
 } bbp_status;
 
 #define BBP_MIMC_ROUNDS 90      /* src/gadgets.rs:4 */
@@ -48,6 +57,9 @@ typedef enum {
  * lazy_static CONSTANTS (src/blindbid/mod.rs:7-24): derives them ONCE on `device` and keeps them resident.
  * `device` is a HIP device ordinal (one context per GPU / per rank). */
 int32_t bbp_init(int32_t device, bbp_ctx** out);
+/* `stream` arguments of the _dev entry points: a hipStream_t of the caller -- NULL is the legacy default stream and is honoured
+ * as such -- or BBP_STREAM_CONTEXT for the context's own (non-blocking) stream. */
+#define BBP_STREAM_CONTEXT ((void*)(intptr_t)-1)
 void bbp_free(bbp_ctx* ctx);
 const char* bbp_last_error(const bbp_ctx* ctx);
 
@@ -63,7 +75,7 @@ int32_t bbp_msm_batch(bbp_ctx* ctx, uint32_t B, uint32_t n_terms, const uint8_t*
                       uint8_t* out32);
 
 /* Device-resident variant used by bench.py so the timed region starts with inputs in HBM: same semantics with
- * `scalars_dev` / `out32_dev` being device pointers; `stream` is a hipStream_t (0 = context stream); does not
+ * `scalars_dev` / `out32_dev` being device pointers; `stream` is a hipStream_t (or BBP_STREAM_CONTEXT); does not
  * synchronise.  The device scalars cannot be screened on the host: they MUST be canonical (< l < 2^253) -- the recoding
  * only looks at bits 0..255 and silently drops a final carry, so a non-canonical scalar yields a wrong point (never a fault).
  * Scratch is grown inside the context on first use of a batch shape. */
@@ -110,7 +122,7 @@ int32_t bbp_prove_batch(bbp_ctx* ctx, uint32_t B, uint32_t N, const uint8_t* in,
 int32_t bbp_verify_batch(bbp_ctx* ctx, uint32_t B, uint32_t N, const uint8_t* in, int32_t* status);
 
 /* Device-resident variants (bench.py / pipelined callers): same record layouts, every pointer a device pointer,
- * `stream` a hipStream_t (0 = context stream), no host synchronisation, no host-side argument screening
+ * `stream` a hipStream_t (or BBP_STREAM_CONTEXT), no host synchronisation, no host-side argument screening
  * (toggle < N and canonical inputs are the caller's responsibility).  in_dev / entropy_dev must be COMPLETE when the call
  * is made: the prover's opening stage (witness, commitments, transcript rng) starts at once on an internal stream so that
  * it overlaps the previous call's MSM stage; outputs are ordered on `stream` as usual: complete for anything enqueued on
@@ -132,6 +144,19 @@ int32_t bbp_verify_batch_aggregated(bbp_ctx* ctx, uint32_t B, uint32_t N, const 
                                     uint32_t* n_fallback);
 int32_t bbp_verify_batch_aggregated_dev(bbp_ctx* ctx, uint32_t B, uint32_t N, const void* in_dev, const void* entropy_dev,
                                         void* status_dev, uint32_t group, uint32_t* n_fallback, void* stream);
+
+/* Micro-batching window of the call combiner, microseconds (default 0: a batch leaves as soon as the engine is free).  With a
+ * window the leader of a batch waits that long for more concurrent bbp_prove / bbp_verify callers before it goes to the device --
+ * what the UDS server (server/) uses to turn concurrent connections into GPU batches.  max_batch bounds one combined call. */
+int32_t bbp_set_batching(bbp_ctx* ctx, uint32_t window_us, uint32_t max_batch);
+/* Combiner statistics since bbp_init: combined device calls issued / requests they carried / largest batch (any may be NULL). */
+int32_t bbp_batching_stats(bbp_ctx* ctx, uint64_t* n_calls, uint64_t* n_requests, uint32_t* max_seen);
+
+/* Host-only synthesis check (no context, no device): compiles the blind-bid circuit for list length N exactly as bbp_prove would
+ * (csrc/circuit.h mirrors src/gadgets.rs) and reports its size: n_mul = 1442 + 3N, n_cons = 2 n_mul + 3 + 3N.  N == 0 is
+ * BBP_ERR_BAD_ARG (the reference panics at src/gadgets.rs:103), N > 202 BBP_ERR_GENS_LEN.  Also the place where the exception
+ * barrier can be exercised without a GPU (BBP_FAULT_INJECT=compile in the environment makes the synthesis throw). */
+int32_t bbp_debug_compile_circuit(uint32_t N, uint32_t* n_mul, uint32_t* n_cons);
 
 /* Parity hook: the 32-scalar challenge block of proof `proof` of the LAST batch call of geometry (B, N):
  * y z u x w y^-1 t1..t6 tb1..tb6 t_x t_x~ e~ ... (MiscSlot order in csrc/batch.h), 32 x 32 bytes. */

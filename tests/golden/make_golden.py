@@ -48,7 +48,38 @@ def case(name, rounds, cap, N, toggle):
                 proof_len=len(pr.proof.to_bytes()), record=rec.hex(), trace=trace)
 
 
+def case_noncanonical(name, N, toggle):
+    """SURVEY.md 8a row a9: bid-list entries are 32 raw bytes taken through Scalar::from_bits (src/blindbid/bid.rs:27,
+    verify.rs:115) -- bit 255 cleared, NOT reduced, used mod l downstream.  The list holds l, l + 1, 2^255 - 1, a value with bit
+    255 set and a value >= 2^255 + l beside the bid's own x; `pub_list` in the fixture is the RAW bytes the caller hands over."""
+    cons = bb.mimc_constants()
+    d = int.from_bytes(stream(name.encode() + b"/d", 8), "little")
+    k = rs.sc_wide(stream(name.encode() + b"/k", 64))
+    seed = rs.sc_wide(stream(name.encode() + b"/seed", 64))
+    w = bb.witness(d, k, seed, cons)
+    raw = [L, L + 1, 2**255 - 1, 2**255 + 12345, 2**256 - 1, 2**255 + L + 7][:N]
+    raw = [v.to_bytes(32, "little") for v in raw]
+    while len(raw) < N:
+        raw.append(stream(name.encode() + b"/pub%d" % len(raw), 32))
+    raw[toggle] = rs.sc_bytes(w["x"])
+    pub = [rs.sc_from_bits(b) for b in raw]
+    ent = stream(name.encode() + b"/ent", 32 * (4 + N) + 32)
+    ent = b"".join(rs.sc_bytes(rs.sc_wide(ent[32 * i:32 * i + 32] + bytes(32))) for i in range(4 + N)) + ent[32 * (4 + N):]
+    trace = {}
+    pr = bb.prove(d, k, w["y"], w["y_inv"], w["q"], w["z_img"], seed, pub, toggle, ent, trace=trace)
+    rec = pr.to_record()
+    assert bb.verify(bb.Proof.from_record(rec, N), w["q"], w["z_img"], seed, pub, bytes(32))
+    sc = lambda v: rs.sc_bytes(v).hex()
+    return dict(name=name, rounds=90, cap=2048, N=N, toggle=toggle, d=sc(d), k=sc(k), seed=sc(seed), y=sc(w["y"]), y_inv=sc(w["y_inv"]),
+                q=sc(w["q"]), z_img=sc(w["z_img"]), pub_list=[b.hex() for b in raw], entropy=ent.hex(),
+                proof_len=len(pr.proof.to_bytes()), record=rec.hex(), trace=trace)
+
+
 def main():
+    if "--noncanonical" in sys.argv:
+        out = {"noncanonical": [case_noncanonical("noncanon_n7", 7, 4)]}
+        json.dump(out, open(os.path.join(HERE, "proofs_noncanonical.json"), "w"), indent=1)
+        return
     full = "--full" in sys.argv
     out = {"small": [case("r2n3", 2, 64, 3, 1), case("r3n1", 3, 64, 1, 0), case("r1n5", 1, 64, 5, 4)]}
     json.dump(out, open(os.path.join(HERE, "proofs_small.json"), "w"), indent=1)

@@ -29,6 +29,10 @@ def test_engine_addition_counts_are_consistent():
     assert 6.8e5 < adds < 7.2e5                         # ~0.70 M mixed additions per proof
 
 
-def test_measured_traffic_constant_is_per_launch_bytes():
-    t = bw.MEASURED_TRAFFIC_PROVE_1024_8
-    assert t is None or 1e9 < t < 2e10
+def test_measured_traffic_comes_from_a_named_profile():
+    """roofline.traffic is never a constant in the code: it is read from profiles/traffic.json (written from the rocprofv3 PMC
+    passes by tools/pmc_aggregate.py) together with the name of the profile it came from, or it is null."""
+    import os
+    t, src = bw._traffic_from_profiles("prove_b1024_n8")
+    assert t is None or (1e8 < t < 2e10 and src.startswith("profiles/") and os.path.exists(os.path.join(bw.ROOT, src.split(" ")[0])))
+    assert bw._traffic_from_profiles("no such workload") == (None, None)

@@ -46,3 +46,24 @@ def test_product_does_not_reference_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "oracle/" not in txt and "from oracle" not in txt and "import oracle" not in txt and "bbp_oracle" not in txt, f
+
+
+def test_circuit_synthesis_sizes_and_statuses(bbp):
+    """Host-only synthesis through the C ABI (no device): n_mul = 1442 + 3N, n_cons = 2 n_mul + 3 + 3N; the states
+    the reference panics on / rejects come back as statuses."""
+    from dusk_blindbidproof_amd._native import compile_circuit
+    for n in (1, 3, 8, 40, 202):
+        rc, n_mul, n_cons = compile_circuit(n)
+        assert (rc, n_mul, n_cons) == (0, 1442 + 3 * n, 2 * (1442 + 3 * n) + 3 + 3 * n), n
+    assert compile_circuit(0)[0] == 4      # empty list: the reference panics at src/gadgets.rs:103
+    assert compile_circuit(203)[0] == 2    # R1CSError::InvalidGeneratorsLength
+
+
+def test_exception_barrier_turns_a_throw_into_a_status(bbp, monkeypatch):
+    """include/bbp.h promises that nothing throws across the boundary: force circuit::compile to throw (the same code path
+    bbp_prove / bbp_verify take for a list length they have not compiled yet) and see BBP_ERR_INTERNAL, not a crash."""
+    from dusk_blindbidproof_amd._native import compile_circuit
+    monkeypatch.setenv("BBP_FAULT_INJECT", "compile")
+    assert compile_circuit(8)[0] == 6
+    monkeypatch.delenv("BBP_FAULT_INJECT")
+    assert compile_circuit(8)[0] == 0

@@ -228,7 +228,7 @@ def test_prepare_bids_on_device_feeds_prove_and_verify(ctx, oc, bbp, N, B):
     status = torch.full((B,), -1, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
     # no host synchronisation from here on: the bid pass on a stream of its own (as a pipelined caller would run it), prove /
-    # verify on another (a real stream: handle 0 would mean the context's internal stream, which torch's copies are not ordered with)
+    # verify on another
     prep, main = torch.cuda.Stream(), torch.cuda.Stream()
     ctx.prepare_bids_dev(B, N, d_bids.data_ptr(), d_lists.data_ptr(), d_tog.data_ptr(), d_in.data_ptr(), d_vt.data_ptr(), prep.cuda_stream)
     with torch.cuda.stream(main):

@@ -100,6 +100,21 @@ def test_full_golden(oc, golden):
         _run_case(oc, c)
 
 
+def test_noncanonical_bid_list_golden(oc, golden):
+    """SURVEY.md 8a row a9 (Scalar::from_bits, src/blindbid/bid.rs:20-29, verify.rs:112-116): the fixture's list holds l, l + 1,
+    2^255 - 1 and values with bit 255 set as RAW bytes; the C restatement reproduces the big-int oracle's bytes, and the list
+    reduced by hand is the same statement."""
+    c = golden("proofs_noncanonical.json")["noncanonical"][0]
+    raw = [bytes.fromhex(p) for p in c["pub_list"]]
+    vals = [int.from_bytes(b, "little") for b in raw]
+    assert L in vals and L + 1 in vals and 2**255 - 1 in vals and any(v >> 255 for v in vals)
+    _run_case(oc, c)
+    s7 = b"".join(bytes.fromhex(c[k]) for k in ["d", "k", "y", "y_inv", "q", "z_img", "seed"])
+    reduced = b"".join(rs.sc_bytes(rs.sc_from_bits(b)) for b in raw)
+    rc, rec = oc.prove(s7, reduced, c["toggle"], bytes.fromhex(c["entropy"]))
+    assert rc == 0 and rec.hex() == c["record"]
+
+
 def test_bad_args(oc):
     s7 = bytes(7 * 32)
     assert oc.prove(s7, b"", 0, bytes(32 * 5))[0] == 4
