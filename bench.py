@@ -226,13 +226,27 @@ def main():
         ctx, bbp, wl, stream, engine_stream = None, None, StubWorkload(args.batch), None, None
     else:
         import dusk_blindbidproof_amd as bbp
+        if os.environ.get("BBP_BENCH_STREAM") == "torch_first":
+            pre_stream = torch.cuda.Stream()  # experiment: torch's stream pool exists before the engine's streams
         ctx = bbp.Context(dev_index)
         wl = make_workload(args.workload, ctx, bbp, torch, device, args.batch, args.items, seed=1 + rank)
         # a real caller stream (not handle 0): the ordering contract of include/bbp.h is exercised, and torch's own work of this
         # script (copies, clones in the workloads) is issued on the same stream
-        engine_stream = torch.cuda.Stream()
-        torch.cuda.set_stream(engine_stream)
-        stream = engine_stream.cuda_stream
+        mode = os.environ.get("BBP_BENCH_STREAM", "external")
+        if mode == "context":    # experiment knobs (DESIGN.md section 4 "whose stream")
+            engine_stream, stream = None, None
+        elif mode == "torch_first":
+            engine_stream = pre_stream
+            torch.cuda.set_stream(engine_stream)
+            stream = engine_stream.cuda_stream
+        elif mode == "torch":
+            engine_stream = torch.cuda.Stream()
+            torch.cuda.set_stream(engine_stream)
+            stream = engine_stream.cuda_stream
+        else:
+            engine_stream = torch.cuda.ExternalStream(ctx.stream, device=device)
+            torch.cuda.set_stream(engine_stream)
+            stream = engine_stream.cuda_stream
     for _ in range(args.warmup):
         wl.step(stream)
     wl.drain()

@@ -373,7 +373,9 @@ class StreamWorkload(_Base):
         self.h_tog = torch.tensor([i % N for i in range(C)], dtype=torch.int64).pin_memory()
         self.es, self.rec, self.in_stride, self.vt = bbp.entropy_size(N), bbp.record_size(N), 224 + 32 * N + 8, 96 + 32 * N
         self.ent_np = np.frombuffer(bytearray(b"".join(ents[i % tile] for i in range(C))), dtype=np.uint8).reshape(C, self.es).copy()
-        self.cp = torch.cuda.Stream()
+        # ingest side on the context's own second stream (include/bbp.h: a stream from torch's pool may share a hardware queue
+        # with one of the engine's); BBP_BENCH_COPY_STREAM=torch for the comparison
+        self.cp = torch.cuda.Stream() if os.environ.get("BBP_BENCH_COPY_STREAM") == "torch" else torch.cuda.ExternalStream(ctx.copy_stream, device=device)
         z = lambda n, dt=torch.uint8: torch.zeros(n, dtype=dt, device=device)
         self.slots = [dict(h_ent=torch.empty(C * self.es, dtype=torch.uint8).pin_memory(), d_bids=z(C * 96), d_lists=z(C * 32 * N),
                            d_tog=z(C, torch.int64), d_ent=z(C * self.es), d_in=z(C * self.in_stride), d_vt=z(C * self.vt), d_rec=z(C * self.rec),
@@ -401,15 +403,16 @@ class StreamWorkload(_Base):
         self.done_chunks += 1
         sl["busy"] = False
 
-    def step(self, stream):
+    def _stage(self, k):
+        """Host side of the ingest for chunk k, issued one chunk AHEAD of its prove call: with the GPU saturated a copy or the
+        witness kernel can wait milliseconds for its turn, and the prover's opening stage needs complete inputs when it starts."""
         torch, C, N = self.torch, self.B, self.N
-        sl = self.slots[self.k % self.depth]
+        sl = self.slots[k % self.depth]
         if sl["busy"]:
             self._retire(sl)  # the only host wait: the slot used `depth` chunks ago
-        seeds = self.np.frombuffer(hashlib.shake_256(b"chunk%d" % self.k).digest(32 * C), dtype=self.np.uint8).reshape(C, 32)
+        seeds = self.np.frombuffer(hashlib.shake_256(b"chunk%d" % k).digest(32 * C), dtype=self.np.uint8).reshape(C, 32)
         self.ent_np[:, self.es - 32:] = seeds
         sl["h_ent"].copy_(torch.from_numpy(self.ent_np.reshape(-1)))
-        eng = torch.cuda.current_stream()
         with torch.cuda.stream(self.cp):
             sl["ev0"].record(self.cp)
             sl["d_bids"].copy_(self.h_bids, non_blocking=True)
@@ -421,7 +424,16 @@ class StreamWorkload(_Base):
             self.ctx.prepare_bids_dev(C, N, sl["d_bids"].data_ptr(), sl["d_lists"].data_ptr(), sl["d_tog"].data_ptr(), sl["d_in"].data_ptr(),
                                       sl["d_vt"].data_ptr(), self.cp.cuda_stream)
             sl["ev_in"].record(self.cp)
+        sl["chunk"] = k
+
+    def step(self, stream):
+        torch, C, N = self.torch, self.B, self.N
+        sl = self.slots[self.k % self.depth]
+        if sl["chunk"] != self.k:
+            self._stage(self.k)  # first step, or the first after a drain
+        eng = torch.cuda.current_stream()
         self.ctx.prove_batch_dev(C, N, sl["d_in"].data_ptr(), sl["d_ent"].data_ptr(), sl["d_rec"].data_ptr(), stream)
+        self._stage(self.k + 1)  # after the prove call (which waited for ITS bid pass), so the next chunk's ingest runs under this one
         eng.wait_event(sl["ev_in"])  # the verifier tails
         sl["d_vin"][:, :self.rec] = sl["d_rec"].view(C, self.rec)
         sl["d_vin"][:, self.rec:] = sl["d_vt"].view(C, self.vt)
@@ -429,7 +441,7 @@ class StreamWorkload(_Base):
         sl["h_rec"].copy_(sl["d_rec"], non_blocking=True)
         sl["h_st"].copy_(sl["d_st"], non_blocking=True)
         sl["ev1"].record(eng)
-        sl["busy"], sl["chunk"] = True, self.k
+        sl["busy"] = True
         self.k += 1
 
     def drain(self):
@@ -437,6 +449,9 @@ class StreamWorkload(_Base):
             sl = self.slots[(self.k + i) % self.depth]
             if sl["busy"]:
                 self._retire(sl)
+        self.torch.cuda.synchronize()
+        for sl in self.slots:
+            sl["chunk"] = -1  # the chunk staged ahead is dropped: whatever step comes next stages its own (fresh ev0)
 
     def check(self):
         if self.failed:

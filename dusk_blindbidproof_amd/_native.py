@@ -23,6 +23,8 @@ SIGNATURES = {
     "bbp_init": (_i32, [_i32, ctypes.POINTER(_vp)]),
     "bbp_free": (None, [_vp]),
     "bbp_last_error": (_cp, [_vp]),
+    "bbp_context_stream": (_vp, [_vp]),
+    "bbp_context_copy_stream": (_vp, [_vp]),
     "bbp_get_generator": (_i32, [_vp, _u32, _vp]),
     "bbp_get_mimc_constant": (_i32, [_vp, _u32, _vp]),
     "bbp_msm_batch": (_i32, [_vp, _u32, _u32, _vp, _u32, _vp]),
@@ -124,6 +126,16 @@ class Context:
     @property
     def handle(self):
         return self._h
+
+    @property
+    def stream(self):
+        """hipStream_t handle of the context's own stream (wrap it with torch.cuda.ExternalStream to enqueue torch work on it)."""
+        return lib.bbp_context_stream(self._h)
+
+    @property
+    def copy_stream(self):
+        """hipStream_t handle of the context's idle second stream, for the caller's ingest copies / bbp_prepare_bids_dev."""
+        return lib.bbp_context_copy_stream(self._h)
 
     def generator(self, index):
         out = (ctypes.c_uint8 * 32)()

@@ -189,9 +189,13 @@ extern "C" int32_t bbp_prepare_bids_dev(bbp_ctx* ctx, uint32_t B, uint32_t N, co
         if (B == 0) return BBP_OK;
         BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
         hipStream_t s = pick_stream(ctx, stream);
+        // one lane per bid, 4 x 90 sequential MiMC rounds: a serial wave that lives for milliseconds.  In a pipeline it runs beside
+        // another chunk's MSM stage, so it is fenced onto CUs of its own like the prover's opening kernels
+        if ((rc = serial_lds_bytes(ctx, (const void*)k_prepare_bids))) return rc;
+        const unsigned hog = ctx->serial_lds > 0 ? (unsigned)ctx->serial_lds : 0u;
         {
             ScopedEvent ev(ctx, TAG_WITNESS, s);
-            hipLaunchKernelGGL(k_prepare_bids, dim3((B + 63) / 64), dim3(64), 0, s, B, N, (const u8*)bids_dev, (const u8*)lists_dev,
+            hipLaunchKernelGGL(k_prepare_bids, dim3((B + 63) / 64), dim3(64), hog, s, B, N, (const u8*)bids_dev, (const u8*)lists_dev,
                                (const u64*)toggles_dev, ctx->mimc_c, (u32*)prove_in_dev, (u32*)verify_tail_dev);
             BBP_HIP_TRY(ctx, hipGetLastError());
         }

@@ -67,6 +67,7 @@ struct bbp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;            // opening stage of the prover pipeline (prover.hip)
+    hipStream_t copy = nullptr;            // the caller's ingest stream (bbp_context_copy_stream): never used by the engine
     hipStream_t side2 = nullptr;           // second opening stream: batches too small to fill three heavy slices alternate between the two
     int varbase_lanes = 65536;             // lanes the verifier's variable-base kernel is launched with (BBP_VARBASE_LANES): ~1 wave per SIMD
     int dual_open_below = 1024;            // batches smaller than this open on alternating streams (BBP_DUAL_OPEN_BELOW, 0 = never)
@@ -166,6 +167,17 @@ struct ScopedEvent {  // records start now, stop at scope exit, when profiling i
 
 // see prover.hip "serial_lds_bytes": kernels that must not share a CU with the long-lived serial waves ask for a few bytes of LDS
 inline unsigned lds_token(const bbp_ctx* ctx) { return ctx->serial_lds >= 160 * 1024 ? 64u : 0u; }
+
+// One-lane-per-item serial kernels that run beside the MSM stage ask for (nearly) a whole CU's LDS so that nothing else is placed
+// on their CU (prover.hip "Serial waves get their own CUs"): raise the kernel's dynamic-LDS limit once per kernel.
+inline int32_t serial_lds_bytes(bbp_ctx* ctx, const void* kernel) {
+    if (ctx->serial_lds <= 0) return BBP_OK;
+    if (!ctx->serial_attr.count(kernel)) {
+        BBP_HIP_TRY(ctx, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->serial_lds));
+        ctx->serial_attr[kernel] = 1;
+    }
+    return BBP_OK;
+}
 
 // Calls on one context share scratch: a call issued on a different caller stream than the previous one is ordered behind it.
 // RAII so that every exit path -- error returns included -- leaves ev_last recorded on the stream that may have work queued.

@@ -1062,15 +1062,6 @@ static merlin_transcript prover_prefix() {
 // the MSM kernel 3.3 ms -> 19.5 ms while the rng kernel is resident; 107 ms -> 78 ms per batch without it).  So these launches ask for
 // nearly a whole CU's LDS, which they never touch: no LDS-using workgroup (every heavy kernel that matters) can be placed
 // beside them, the dispatcher routes those to the other ~240 CUs, and the serial wave has its CU to itself.
-static int32_t serial_lds_bytes(bbp_ctx* ctx, const void* kernel) {
-    if (ctx->serial_lds <= 0) return 0;
-    if (!ctx->serial_attr.count(kernel)) {
-        BBP_HIP_TRY(ctx, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->serial_lds));
-        ctx->serial_attr[kernel] = 1;
-    }
-    return BBP_OK;
-}
-
 static inline u32 cdiv(u32 a, u32 b) { return (a + b - 1) / b; }
 
 int32_t tail_btab_build(bbp_ctx* ctx) {  // called once from bbp_init: the table of B for the c w B term of the tail rounds

@@ -140,6 +140,7 @@ static int32_t init_body(int32_t device, bbp_ctx** out) {
     }
     BBP_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     BBP_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+    BBP_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking));
     for (int i = 1; i < bbp_ctx::MAX_SLICES; i++) {
         BBP_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->lane[i], hipStreamNonBlocking));
         BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming));
@@ -239,6 +240,7 @@ extern "C" void bbp_free(bbp_ctx* ctx) {
     if (ctx->ev_vfork) (void)hipEventDestroy(ctx->ev_vfork);
     if (ctx->ev_vjoin) (void)hipEventDestroy(ctx->ev_vjoin);
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
+    if (ctx->copy) (void)hipStreamDestroy(ctx->copy);
     if (ctx->side2) (void)hipStreamDestroy(ctx->side2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -259,6 +261,9 @@ extern "C" const char* bbp_last_error(const bbp_ctx* ctx) {
         return "error text unavailable";
     }
 }
+
+extern "C" void* bbp_context_stream(bbp_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+extern "C" void* bbp_context_copy_stream(bbp_ctx* ctx) { return ctx ? (void*)ctx->copy : nullptr; }
 
 extern "C" int32_t bbp_get_generator(bbp_ctx* ctx, uint32_t index, uint8_t out32[32]) {
     if (!ctx || index >= BBP_NUM_BASES) return BBP_ERR_BAD_ARG;
