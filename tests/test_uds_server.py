@@ -1,0 +1,150 @@
+"""not-gpu tier: the UDS front end (dusk_blindbidproof_amd/server/) against a STUB engine -- framing, opcode dispatch, the
+reference's error behaviour (src/futures/main.rs:64-110: prove error -> nothing written, verify failure or malformed -> [0x00],
+unknown opcode -> nothing written) and micro-batching of concurrent connections through the product's call combiner.
+The GPU tier runs the same client against the real engine (tests/test_gpu_uds.py)."""
+import os
+import re
+import signal
+import subprocess
+import tempfile
+import threading
+import time
+
+import pytest
+
+from tests import uds_client as uc
+
+
+@pytest.fixture(scope="module")
+def server(built):
+    built.build_server()
+    stub = built.build_stub_engine()
+    d = tempfile.mkdtemp(prefix="bbp-uds-")
+    path = os.path.join(d, "sock")
+    err = open(os.path.join(d, "log"), "w+")
+    p = subprocess.Popen([built.SERVER_BIN, "-b", path, "-l", "info", "--engine", stub, "--window-us", "2000"], stderr=err)
+    for _ in range(200):
+        if os.path.exists(path):
+            break
+        time.sleep(0.02)
+    assert os.path.exists(path), "server did not bind"
+    yield {"path": path, "proc": p, "log": err}
+    if p.poll() is None:
+        p.send_signal(signal.SIGTERM)
+        p.wait(timeout=10)
+
+
+def _bid(i, n):
+    s7 = b"".join(bytes([(7 * i + k) & 0xff]) * 31 + b"\x01" for k in range(7))
+    pub = b"".join(bytes([(11 * i + j) & 0xff]) * 31 + b"\x02" for j in range(n))
+    return s7, pub, i % n
+
+
+def test_prove_then_verify_over_the_socket(server):
+    s7, pub, toggle = _bid(3, 8)
+    blob = uc.prove(server["path"], s7, pub, toggle)
+    assert blob is not None
+    proof, c, t = uc.decode_proof(blob)
+    assert len(proof) == 1121 and proof[0] == 0 and len(c) == 4 and len(t) == 8 and all(len(x) == 32 for x in c + t)
+    score, z_img, seed = s7[128:160], s7[160:192], s7[192:224]
+    assert uc.verify(server["path"], blob, score, z_img, seed, pub) == b"\x01"
+    bad = bytearray(blob)
+    bad[100] ^= 1
+    assert uc.verify(server["path"], bytes(bad), score, z_img, seed, pub) == b"\x00"          # verification failure
+    assert uc.verify(server["path"], blob, z_img, z_img, seed, pub) == b"\x00"                 # wrong score
+
+
+def test_verify_answers_0x00_to_anything_malformed(server):
+    """main.rs:94-101: `Verify::try_from_reader_variables(..).and_then(verify).is_ok()` -- parse errors are a 0x00 reply too."""
+    s7, pub, toggle = _bid(5, 3)
+    blob = uc.prove(server["path"], s7, pub, toggle)
+    score, z_img, seed = s7[128:160], s7[160:192], s7[192:224]
+    for frame in (uc.tlv(b"\x02"),                                                   # nothing after the opcode
+                  uc.tlv(b"\x02" + b"\x09garbage"),                                  # not even a TLV header
+                  uc.tlv(b"\x02" + uc.tlv(blob) + uc.tlv(score)),                    # truncated
+                  uc.tlv(b"\x02" + uc.tlv(blob) + uc.tlv(score[:31]) + uc.tlv(z_img) + uc.tlv(seed) + uc.tlv_list([pub[:32]] * 3)),  # 31-byte scalar
+                  uc.tlv(b"\x02" + uc.tlv(blob) + uc.tlv(score) + uc.tlv(z_img) + uc.tlv(seed) + uc.tlv_list([pub[:31]] * 3)),       # 31-byte list item
+                  uc.tlv(b"\x02" + uc.tlv(blob) + uc.tlv(score) + uc.tlv(z_img) + uc.tlv(seed) + uc.tlv_list([pub[:32]] * 2))):      # list shorter than t_c
+        c = uc.Conn(server["path"])
+        c.send(frame)
+        assert c.recv_frame() == b"\x00"
+        c.close()
+    # a commitment that is not 32 bytes (proof.rs:158-162) and a blob with three commitments
+    proof, cm, t = uc.decode_proof(blob)
+    for forged in (uc.tlv(proof) + uc.tlv_list([cm[0][:31]] + cm[1:]) + uc.tlv_list(t), uc.tlv(proof) + uc.tlv_list(cm[:3]) + uc.tlv_list(t)):
+        assert uc.verify(server["path"], forged, score, z_img, seed, pub) == b"\x00"
+    # extra public-list entries beyond the toggle commitments are never read by the gadget (gadgets.rs:97-131)
+    assert uc.verify(server["path"], blob, score, z_img, seed, pub + pub[:32]) == b"\x01"
+
+
+def test_prove_errors_write_nothing(server):
+    """main.rs:86-92, 15-25: any prove-side error resolves to Message::Error -- the peer sees the connection close, no payload."""
+    s7, pub, toggle = _bid(9, 4)
+    nc = bytearray(s7)
+    nc[31] = 0xff                                                              # non-canonical d: serde Scalar refuses it
+    bad_frames = [uc.prove_request(bytes(nc), pub, toggle),
+                  uc.prove_request(s7, pub, 4),                               # toggle >= N: typed API cannot express it
+                  uc.tlv(b"\x01" + b"".join(uc.tlv(s7[32 * i:32 * i + 32]) for i in range(7)) + uc.tlv_list([pub[:31]]) + uc.tlv(bytes(8))),  # 31-byte bid
+                  uc.tlv(b"\x01" + b"".join(uc.tlv(s7[32 * i:32 * i + 32]) for i in range(6))),                                             # six scalars
+                  uc.tlv(b"\x01" + b"".join(uc.tlv(s7[32 * i:32 * i + 32]) for i in range(7)) + uc.tlv_list([]) + uc.tlv(bytes(8))),       # empty list
+                  uc.tlv(b"\x07hello"),                                       # undefined operation code (main.rs:102-105)
+                  uc.tlv(b""),                                                # empty request
+                  b"\x03\x00\x00\x00"]                                        # not a frame header at all
+    for f in bad_frames:
+        c = uc.Conn(server["path"])
+        c.send(f)
+        assert c.recv_frame() is None
+        c.close()
+    assert uc.prove(server["path"], s7, pub, toggle) is not None               # and the server is still serving
+
+
+def test_one_connection_may_carry_several_requests(server):
+    s7, pub, toggle = _bid(21, 2)
+    c = uc.Conn(server["path"])
+    for _ in range(3):
+        c.send(uc.prove_request(s7, pub, toggle))
+        blob = c.recv_frame()
+        c.send(uc.verify_request(blob, s7[128:160], s7[160:192], s7[192:224], pub))
+        assert c.recv_frame() == b"\x01"
+    c.close()
+
+
+def test_concurrent_connections_are_micro_batched(server):
+    """48 connections at once: every reply correct, and the device-call count the server logs at shutdown is far below the
+    request count -- concurrent connections became batches (this must be the LAST test: it stops the server to read the log)."""
+    T, per, N = 48, 4, 8
+    errors, replies = [], {}
+
+    def worker(t):
+        try:
+            for j in range(per):
+                s7, pub, toggle = _bid(100 + t * per + j, N)
+                blob = uc.prove(server["path"], s7, pub, toggle)
+                ok = uc.verify(server["path"], blob, s7[128:160], s7[160:192], s7[192:224], pub)
+                replies[(t, j)] = (blob is not None and len(uc.decode_proof(blob)[2]) == N, ok)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errors, errors[:3]
+    assert len(replies) == T * per and all(v == (True, b"\x01") for v in replies.values())
+    server["proc"].send_signal(signal.SIGTERM)
+    server["proc"].wait(timeout=10)
+    server["log"].seek(0)
+    log = server["log"].read()
+    m = re.search(r"served (\d+) requests \((\d+) errors\) in (\d+) device calls, largest batch (\d+)", log)
+    assert m, log[-500:]
+    served, errs, calls, biggest = map(int, m.groups())
+    assert served >= 2 * T * per and calls < served // 2 and biggest >= 4, m.group(0)
+
+
+def test_cli_mirrors_the_reference_flags(built):
+    built.build_server()
+    p = subprocess.run([built.SERVER_BIN, "-l", "loud"], capture_output=True, text=True)
+    assert p.returncode == 2 and "invalid log level" in p.stderr           # clap possible_values (src/main.rs:33)
+    p = subprocess.run([built.SERVER_BIN, "--engine", "/nonexistent.so", "-b", "/tmp/bbp-nope"], capture_output=True, text=True)
+    assert p.returncode == 1 and "cannot load engine" in p.stderr
