@@ -1,6 +1,9 @@
 // C-ABI: prove / verify / witness entry points -- see include/bbp.h for the reference interface each replaces.
 #include <stdio.h>
 #include <string.h>
+#include <unistd.h>
+
+#include <chrono>
 
 #include "batch.h"
 #include "submit.h"
@@ -206,14 +209,100 @@ extern "C" int32_t bbp_prepare_bids_dev(bbp_ctx* ctx, uint32_t B, uint32_t N, co
     });
 }
 
-// body of bbp_prove_batch; the context lock is held by the caller
+// ---- host-pointer batch calls: two staging slots, lock held only while enqueueing (context.h IoSlot) ---------------------------
+namespace bbp {
+struct SlotLease {
+    bbp_ctx* ctx;
+    bbp_ctx::IoSlot* sl;
+    explicit SlotLease(bbp_ctx* c) : ctx(c) {
+        std::unique_lock<std::mutex> lk(c->io_mu);
+        const uint32_t want = c->io_next++ % bbp_ctx::IO_SLOTS;  // strict alternation keeps two consecutive calls on different slots
+        c->io_cv.wait(lk, [&] { return !c->io[want].busy; });
+        sl = &c->io[want];
+        sl->busy = true;
+    }
+    ~SlotLease() {
+        {
+            std::lock_guard<std::mutex> lk(ctx->io_mu);
+            sl->busy = false;
+        }
+        ctx->io_cv.notify_all();
+    }
+};
+// Wait for a slot's results WITHOUT parking inside the HIP runtime: a thread blocked in hipEventSynchronize / hipStreamSynchronize
+// keeps other threads' launches on that stream waiting (measured: two threads calling bbp_prove_batch got no overlap at all,
+// 90 ms per 1024-proof batch either way), which is exactly what the second staging slot is there to allow.  Polling the event
+// leaves the runtime free between polls; BBP_WAIT_POLL_US (default 100) is the sleep between them.
+static hipError_t wait_event_polling(hipEvent_t ev) {
+    static const int poll_us = [] {
+        const char* e = getenv("BBP_WAIT_POLL_US");
+        return e ? atoi(e) : 100;
+    }();
+    if (poll_us <= 0) return hipEventSynchronize(ev);
+    for (;;) {
+        const hipError_t q = hipEventQuery(ev);
+        if (q != hipErrorNotReady) return q;
+        usleep((useconds_t)poll_us);
+    }
+}
+
+static int32_t pinned_reserve(bbp_ctx* ctx, void*& p, size_t& cap, size_t bytes) {
+    if (cap >= bytes) return BBP_OK;
+    if (p) BBP_HIP_TRY(ctx, hipHostFree(p));
+    p = nullptr;
+    cap = 0;
+    const size_t want = bytes + (bytes >> 3) + 4096;
+    BBP_HIP_TRY(ctx, hipHostMalloc(&p, want, hipHostMallocDefault));
+    cap = want;
+    return BBP_OK;
+}
+// inputs of a host-pointer call: caller's (pageable) memory -> the slot's pinned mirror -> device, on the context's copy stream.
+// The main stream may still be busy with the previous call's MSM stage, and the opening stage of THIS call is meant to run under
+// it; it only needs complete inputs (include/bbp.h), hence the wait -- on the copy's own event, polled.
+static int32_t upload_inputs(bbp_ctx* ctx, bbp_ctx::IoSlot& sl, const uint8_t* a, size_t na, const uint8_t* b, size_t nb) {
+    int32_t rc;
+    if ((rc = dev_reserve(ctx, sl.in, na)) || (rc = dev_reserve(ctx, sl.ent, nb)) || (rc = pinned_reserve(ctx, sl.h_in, sl.h_in_cap, na + nb))) return rc;
+    static const bool trace = getenv("BBP_TRACE") != nullptr;
+    auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now_ms();
+    memcpy(sl.h_in, a, na);
+    memcpy((uint8_t*)sl.h_in + na, b, nb);
+    const double t1 = now_ms();
+    BBP_HIP_TRY(ctx, hipMemcpyAsync(sl.in.p, sl.h_in, na, hipMemcpyHostToDevice, ctx->copy));
+    const double t2 = now_ms();
+    BBP_HIP_TRY(ctx, hipMemcpyAsync(sl.ent.p, (uint8_t*)sl.h_in + na, nb, hipMemcpyHostToDevice, ctx->copy));
+    const double t3 = now_ms();
+    BBP_HIP_TRY(ctx, hipEventRecord(sl.ev_in, ctx->copy));
+    const double t4 = now_ms();
+    BBP_HIP_TRY(ctx, wait_event_polling(sl.ev_in));
+    if (trace) fprintf(stderr, "[bbp trace] upload: memcpy %.2f, copy1 %.2f, copy2 %.2f, record %.2f, wait %.2f ms\n", t1 - t0, t2 - t1, t3 - t2, t4 - t3, now_ms() - t4);
+    return BBP_OK;
+}
+// Second half of a host-pointer call, context lock NOT held: wait for the slot's compute to finish, THEN copy the results down.
+// The copy is issued only now, on the copy stream, on purpose: a D2H copy enqueued behind the kernels would sit at the head of a
+// DMA engine's in-order queue waiting for them, and the NEXT call's input copy -- which that call's opening stage is waiting for
+// -- would queue up behind it (measured: the input copy "took" 87 ms, i.e. the previous batch's whole MSM stage; two host
+// threads got no overlap at all).  Issued after the wait, either copy takes ~0.2 ms whatever the compute queues are doing.
+static int32_t fetch_results(bbp_ctx* ctx, bbp_ctx::IoSlot& sl, size_t bytes) {
+    hipError_t e = wait_event_polling(sl.ev);
+    if (e == hipSuccess) e = hipMemcpyAsync(sl.h_out, sl.out.p, bytes, hipMemcpyDeviceToHost, ctx->copy);
+    if (e == hipSuccess) e = hipEventRecord(sl.ev_in, ctx->copy);
+    if (e == hipSuccess) e = wait_event_polling(sl.ev_in);
+    if (e != hipSuccess) {
+        api_guard(ctx, [&]() -> int32_t { return ctx->err = std::string("collecting results: ") + hipGetErrorString(e), BBP_ERR_DEVICE; });
+        return BBP_ERR_DEVICE;
+    }
+    return BBP_OK;
+}
+}  // namespace bbp
+
+// body of bbp_prove_batch.  Takes the context lock itself, for the enqueue phase only.
 static int32_t prove_batch_host(bbp_ctx* ctx, uint32_t B, uint32_t N, const uint8_t* in, const uint8_t* entropy, uint8_t* out,
                                 int32_t* status) {
-    int32_t rc = check_n(ctx, N);
+    int32_t rc = api_guard(ctx, [&]() -> int32_t { return check_n(ctx, N); });
     if (rc) return rc;
     if (B == 0) return BBP_OK;
     fault_injected("prove_batch");
-    BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t in_stride = 7 * 32 + (size_t)N * 32 + 8, ent_stride = bbp_entropy_size(N), out_stride = bbp_proof_record_size(N);
     // host-side argument screening (the reference's typed API cannot express these states: SURVEY.md 8b)
     std::vector<uint8_t> fixed;
@@ -240,7 +329,7 @@ static int32_t prove_batch_host(bbp_ctx* ctx, uint32_t B, uint32_t N, const uint
         const uint32_t m = 4 + N;
         std::vector<uint8_t> raw((size_t)B * (64 * m + 32));
         if (!os_random(raw.data(), raw.size())) {
-            ctx->err = "cannot read /dev/urandom";
+            api_guard(ctx, [&]() -> int32_t { return ctx->err = "cannot read /dev/urandom", BBP_ERR_DEVICE; });
             return BBP_ERR_DEVICE;
         }
         ent_host.resize(ent_stride * B);
@@ -256,37 +345,68 @@ static int32_t prove_batch_host(bbp_ctx* ctx, uint32_t B, uint32_t N, const uint
         }
         entropy = ent_host.data();
     }
-    if ((rc = dev_reserve(ctx, ctx->io_in, in_stride * B)) || (rc = dev_reserve(ctx, ctx->io_ent, ent_stride * B)) ||
-        (rc = dev_reserve(ctx, ctx->io_out, out_stride * B)))
-        return rc;
-    {
-        StreamGuard guard(ctx, ctx->stream);  // io_* may still be read by an earlier call issued on another stream
-        if ((rc = guard.enter())) return rc;
-        BBP_HIP_TRY(ctx, hipMemcpyAsync(ctx->io_in.p, src, in_stride * B, hipMemcpyHostToDevice, ctx->stream));
-        BBP_HIP_TRY(ctx, hipMemcpyAsync(ctx->io_ent.p, entropy, ent_stride * B, hipMemcpyHostToDevice, ctx->stream));
-        BBP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors may go out of scope
-    }
-    // Very large host batches go through the engine in equal chunks of at most host_chunk_prove proofs so that scratch stays
-    // bounded (~1.3 MB per proof of the largest call, three buffers); consecutive calls pipeline -- chunk k+1's opening stage
-    // under chunk k's MSMs.  One 16384-proof call was measured 5 % faster than four of 4096, hence the large default.
-    const uint32_t n_chunks = (B + host_chunk_prove() - 1) / host_chunk_prove(), chunk = (B + n_chunks - 1) / n_chunks;
-    for (uint32_t first = 0; first < B; first += chunk) {
-        const uint32_t nb = B - first < chunk ? B - first : chunk;
-        if ((rc = prove_batch_dev(ctx, nb, N, (const u8*)ctx->io_in.p + in_stride * first, (const u8*)ctx->io_ent.p + ent_stride * first,
-                                  (u8*)ctx->io_out.p + out_stride * first, ctx->stream)))
+    static const bool trace = getenv("BBP_TRACE") != nullptr;
+    auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_enter = now_ms();
+    SlotLease lease(ctx);  // may wait for the call two back to collect its results; the context lock is NOT held here
+    bbp_ctx::IoSlot& sl = *lease.sl;
+    const double t_slot = now_ms();
+    double t_lock = 0, t_h2d = 0;
+    rc = api_guard(ctx, [&]() -> int32_t {
+        int32_t rc;
+        t_lock = now_ms();
+        BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+        if ((rc = dev_reserve(ctx, sl.out, out_stride * B)) || (rc = pinned_reserve(ctx, sl.h_out, sl.h_cap, out_stride * B)) ||
+            (rc = upload_inputs(ctx, sl, src, in_stride * B, entropy, ent_stride * B)))
             return rc;
-    }
-    BBP_HIP_TRY(ctx, hipMemcpyAsync(out, ctx->io_out.p, out_stride * B, hipMemcpyDeviceToHost, ctx->stream));
-    BBP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        t_h2d = now_ms();
+        // Very large host batches go through the engine in equal chunks of at most host_chunk_prove proofs so that scratch stays
+        // bounded (~1.3 MB per proof of the largest call, three buffers); consecutive calls pipeline -- chunk k+1's opening stage
+        // under chunk k's MSMs.  One 16384-proof call was measured 5 % faster than four of 4096, hence the large default.
+        const uint32_t n_chunks = (B + host_chunk_prove() - 1) / host_chunk_prove(), chunk = (B + n_chunks - 1) / n_chunks;
+        for (uint32_t first = 0; first < B; first += chunk) {
+            const uint32_t nb = B - first < chunk ? B - first : chunk;
+            if ((rc = prove_batch_dev(ctx, nb, N, (const u8*)sl.in.p + in_stride * first, (const u8*)sl.ent.p + ent_stride * first,
+                                      (u8*)sl.out.p + out_stride * first, ctx->stream)))
+                return rc;
+        }
+        BBP_HIP_TRY(ctx, hipEventRecord(sl.ev, ctx->stream));
+        return BBP_OK;
+    });
+    if (rc) return rc;
+    const double t_enq = now_ms();
+    if ((rc = fetch_results(ctx, sl, out_stride * B))) return rc;  // lock released: another thread may be enqueueing the next batch now
+    memcpy(out, sl.h_out, out_stride * B);
+    if (trace)
+        fprintf(stderr, "[bbp trace] prove_batch B=%u slot=%d: enter %.1f, slot +%.1f, lock +%.1f, h2d +%.1f, enqueued +%.1f, done +%.1f\n", B,
+                (int)(&sl - ctx->io), t_enter, t_slot - t_enter, t_lock - t_enter, t_h2d - t_enter, t_enq - t_enter, now_ms() - t_enter);
     for (uint32_t i = 0; i < B; i++)
         if (status[i] != BBP_OK) memset(out + out_stride * i, 0, out_stride);
     return BBP_OK;
 }
 
+template <class F>
+static int32_t no_throw_ctx(bbp_ctx* ctx, F&& body) noexcept {  // for bodies that lock in phases: same mapping as api_guard
+    try {
+        return body();
+    } catch (const std::invalid_argument& e) {
+        api_guard(ctx, [&]() -> int32_t { return ctx->err = std::string("invalid argument: ") + e.what(), BBP_ERR_BAD_ARG; });
+        return BBP_ERR_BAD_ARG;
+    } catch (const std::bad_alloc&) {
+        api_guard(ctx, [&]() -> int32_t { return ctx->err = "host allocation failed", BBP_ERR_INTERNAL; });
+        return BBP_ERR_INTERNAL;
+    } catch (const std::exception& e) {
+        api_guard(ctx, [&]() -> int32_t { return ctx->err = std::string("internal error: ") + e.what(), BBP_ERR_INTERNAL; });
+        return BBP_ERR_INTERNAL;
+    } catch (...) {
+        return BBP_ERR_INTERNAL;
+    }
+}
+
 extern "C" int32_t bbp_prove_batch(bbp_ctx* ctx, uint32_t B, uint32_t N, const uint8_t* in, const uint8_t* entropy, uint8_t* out,
                                    int32_t* status) {
     if (!ctx || !in || !out || !status) return BBP_ERR_BAD_ARG;
-    return api_guard(ctx, [&]() -> int32_t { return prove_batch_host(ctx, B, N, in, entropy, out, status); });
+    return no_throw_ctx(ctx, [&]() -> int32_t { return prove_batch_host(ctx, B, N, in, entropy, out, status); });
 }
 
 extern "C" int32_t bbp_prove_batch_dev(bbp_ctx* ctx, uint32_t B, uint32_t N, const void* in_dev, const void* entropy_dev, void* out_dev,
@@ -304,7 +424,7 @@ extern "C" int32_t bbp_prove_batch_dev(bbp_ctx* ctx, uint32_t B, uint32_t N, con
 // what the call combiner runs for a group of concurrent bbp_prove callers (submit.cpp)
 int32_t bbp::prove_batch_locked(bbp_ctx* ctx, uint32_t B, uint32_t N, const uint8_t* in, const uint8_t* entropy, uint8_t* out,
                                 int32_t* status, std::string* err) {
-    const int32_t rc = api_guard(ctx, [&]() -> int32_t { return prove_batch_host(ctx, B, N, in, entropy, out, status); });
+    const int32_t rc = no_throw_ctx(ctx, [&]() -> int32_t { return prove_batch_host(ctx, B, N, in, entropy, out, status); });
     if (rc && err) *err = tls_error();
     return rc;
 }
@@ -338,58 +458,56 @@ extern "C" int32_t bbp_prove(bbp_ctx* ctx, const uint8_t scalars7[7 * 32], const
 }
 
 // rec_ver 0: compact 1121-byte proofs; 1: the 2-phase 1217-byte R1CSProof layout (both parse in the reference)
+// Takes the context lock itself, for the enqueue phase only (aggregated mode synchronises inside it: the host reads group verdicts).
 static int32_t verify_batch_host(bbp_ctx* ctx, uint32_t B, uint32_t N, uint32_t rec_ver, const uint8_t* in, int32_t* status,
                                  uint32_t group = 0, uint32_t* n_fallback = nullptr) {
-    int32_t rc;
-    BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t stride = (size_t)(rec_ver ? 1217u : 1121u) + 32 * (4 + (size_t)N) + 96 + (size_t)N * 32;
     std::vector<uint8_t> ent((size_t)B * 32);
     if (!os_random(ent.data(), ent.size())) {  // Verifier::verify mixes thread_rng into its TranscriptRng (A.7)
-        ctx->err = "cannot read /dev/urandom";
+        api_guard(ctx, [&]() -> int32_t { return ctx->err = "cannot read /dev/urandom", BBP_ERR_DEVICE; });
         return BBP_ERR_DEVICE;
     }
-    if ((rc = dev_reserve(ctx, ctx->io_in, stride * B)) || (rc = dev_reserve(ctx, ctx->io_ent, 32 * (size_t)B)) ||
-        (rc = dev_reserve(ctx, ctx->io_out, 4 * (size_t)B)))
-        return rc;
-    {
-        StreamGuard guard(ctx, ctx->stream);
-        if ((rc = guard.enter())) return rc;
-        BBP_HIP_TRY(ctx, hipMemcpyAsync(ctx->io_in.p, in, stride * B, hipMemcpyHostToDevice, ctx->stream));
-        BBP_HIP_TRY(ctx, hipMemcpyAsync(ctx->io_ent.p, ent.data(), ent.size(), hipMemcpyHostToDevice, ctx->stream));
-        BBP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    }
-    const uint32_t n_chunks = (B + host_chunk_verify() - 1) / host_chunk_verify(), chunk = (B + n_chunks - 1) / n_chunks;
-    for (uint32_t first = 0; first < B; first += chunk) {  // bounded scratch for any B (see bbp_prove_batch)
-        const uint32_t nb = B - first < chunk ? B - first : chunk;
-        const u8 *cin = (const u8*)ctx->io_in.p + stride * first, *cent = (const u8*)ctx->io_ent.p + 32 * (size_t)first;
-        int32_t* cst = (int32_t*)ctx->io_out.p + first;
-        if (group > 1) {
-            uint32_t nf = 0;
-            if ((rc = verify_batch_agg_dev(ctx, nb, N, group, cin, cent, cst, ctx->stream, &nf))) return rc;
-            if (n_fallback) *n_fallback += nf;
-        } else if ((rc = verify_batch_dev_ex(ctx, nb, N, rec_ver, 0, cin, cent, cst, ctx->stream)))
+    SlotLease lease(ctx);
+    bbp_ctx::IoSlot& sl = *lease.sl;
+    int32_t rc = api_guard(ctx, [&]() -> int32_t {
+        int32_t rc;
+        BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+        if ((rc = dev_reserve(ctx, sl.out, 4 * (size_t)B)) || (rc = pinned_reserve(ctx, sl.h_out, sl.h_cap, 4 * (size_t)B)) ||
+            (rc = upload_inputs(ctx, sl, in, stride * B, ent.data(), ent.size())))
             return rc;
-    }
-    BBP_HIP_TRY(ctx, hipMemcpyAsync(status, ctx->io_out.p, 4 * (size_t)B, hipMemcpyDeviceToHost, ctx->stream));
-    BBP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        const uint32_t n_chunks = (B + host_chunk_verify() - 1) / host_chunk_verify(), chunk = (B + n_chunks - 1) / n_chunks;
+        for (uint32_t first = 0; first < B; first += chunk) {  // bounded scratch for any B (see bbp_prove_batch)
+            const uint32_t nb = B - first < chunk ? B - first : chunk;
+            const u8 *cin = (const u8*)sl.in.p + stride * first, *cent = (const u8*)sl.ent.p + 32 * (size_t)first;
+            int32_t* cst = (int32_t*)sl.out.p + first;
+            if (group > 1) {
+                uint32_t nf = 0;
+                if ((rc = verify_batch_agg_dev(ctx, nb, N, group, cin, cent, cst, ctx->stream, &nf))) return rc;
+                if (n_fallback) *n_fallback += nf;
+            } else if ((rc = verify_batch_dev_ex(ctx, nb, N, rec_ver, 0, cin, cent, cst, ctx->stream)))
+                return rc;
+        }
+        BBP_HIP_TRY(ctx, hipEventRecord(sl.ev, ctx->stream));
+        return BBP_OK;
+    });
+    if (rc) return rc;
+    if ((rc = fetch_results(ctx, sl, 4 * (size_t)B))) return rc;
+    memcpy(status, sl.h_out, 4 * (size_t)B);
     return BBP_OK;
 }
 
 int32_t bbp::verify_batch_locked(bbp_ctx* ctx, uint32_t B, uint32_t N, uint32_t rec_ver, const uint8_t* in, int32_t* status,
                                  std::string* err) {
-    const int32_t rc = api_guard(ctx, [&]() -> int32_t { return verify_batch_host(ctx, B, N, rec_ver, in, status); });
+    const int32_t rc = no_throw_ctx(ctx, [&]() -> int32_t { return verify_batch_host(ctx, B, N, rec_ver, in, status); });
     if (rc && err) *err = tls_error();
     return rc;
 }
 
 extern "C" int32_t bbp_verify_batch(bbp_ctx* ctx, uint32_t B, uint32_t N, const uint8_t* in, int32_t* status) {
     if (!ctx || !in || !status) return BBP_ERR_BAD_ARG;
-    return api_guard(ctx, [&]() -> int32_t {
-        int32_t rc = check_n(ctx, N);
-        if (rc) return rc;
-        if (B == 0) return BBP_OK;
-        return verify_batch_host(ctx, B, N, 0, in, status);
-    });
+    int32_t rc = api_guard(ctx, [&]() -> int32_t { return check_n(ctx, N); });
+    if (rc || B == 0) return rc;
+    return no_throw_ctx(ctx, [&]() -> int32_t { return verify_batch_host(ctx, B, N, 0, in, status); });
 }
 
 extern "C" int32_t bbp_verify_batch_dev(bbp_ctx* ctx, uint32_t B, uint32_t N, const void* in_dev, const void* entropy_dev,
@@ -408,12 +526,9 @@ extern "C" int32_t bbp_verify_batch_aggregated(bbp_ctx* ctx, uint32_t B, uint32_
                                                uint32_t* n_fallback) {
     if (n_fallback) *n_fallback = 0;
     if (!ctx || !in || !status) return BBP_ERR_BAD_ARG;
-    return api_guard(ctx, [&]() -> int32_t {
-        int32_t rc = check_n(ctx, N);
-        if (rc) return rc;
-        if (B == 0) return BBP_OK;
-        return verify_batch_host(ctx, B, N, 0, in, status, group ? group : BBP_AGG_GROUP_DEFAULT, n_fallback);
-    });
+    int32_t rc = api_guard(ctx, [&]() -> int32_t { return check_n(ctx, N); });
+    if (rc || B == 0) return rc;
+    return no_throw_ctx(ctx, [&]() -> int32_t { return verify_batch_host(ctx, B, N, 0, in, status, group ? group : BBP_AGG_GROUP_DEFAULT, n_fallback); });
 }
 
 extern "C" int32_t bbp_verify_batch_aggregated_dev(bbp_ctx* ctx, uint32_t B, uint32_t N, const void* in_dev, const void* entropy_dev,

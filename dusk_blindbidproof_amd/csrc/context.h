@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <condition_variable>
 #include <map>
 #include <mutex>
 #include <new>
@@ -110,6 +111,22 @@ struct bbp_ctx {
     bbp::DevBuf slice_sorted[MAX_SLICES], slice_pts[MAX_SLICES], slice_fold[MAX_SLICES], slice_vtab[MAX_SLICES];  // per-slice MSM scratch (slice 0 uses sorted / pts)
     void *agg_vs = nullptr, *agg_varsum = nullptr;  // weighted generator scalars [B][4098] / per-proof variable-base sums of that pass
     int32_t* agg_gstatus = nullptr;  // per-group verdicts of the last aggregated verification (inside agg)
+    // Host-pointer batch calls stage through one of two slots (device in / entropy / out + a pinned host mirror of the results):
+    // a call holds the context lock only while it ENQUEUES; it waits for its results on the slot's event with the lock released,
+    // so a second host thread can enqueue the next batch meanwhile and the engine's cross-call pipeline (opening stage of call
+    // k+1 under the MSM stage of call k) also works for bbp_prove_batch / bbp_prove / the UDS server (capi_prove.hip).
+    struct IoSlot {
+        bbp::DevBuf in, ent, out;
+        void *h_out = nullptr, *h_in = nullptr;  // pinned mirrors: results / inputs (a copy from PAGEABLE memory waits for the whole
+        size_t h_cap = 0, h_in_cap = 0;          // device to go idle -- measured 87 ms behind a running batch -- a pinned one does not)
+        hipEvent_t ev = nullptr, ev_in = nullptr;
+        bool busy = false;
+    };
+    static constexpr int IO_SLOTS = 2;
+    IoSlot io[IO_SLOTS];
+    std::mutex io_mu;
+    std::condition_variable io_cv;
+    uint32_t io_next = 0;
     std::map<uint32_t, void*> circuits;  // N -> CircuitDev* (compiled blind-bid circuit tables on the device)
     std::map<uint64_t, bbp::u32*> layout_idx;  // (layout << 32 | n_terms) -> device base-index list of bbp_msm_batch (capi_msm.hip)
     std::vector<float> timings;

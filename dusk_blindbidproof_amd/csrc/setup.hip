@@ -147,6 +147,10 @@ static int32_t init_body(int32_t device, bbp_ctx** out) {
         BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_stagger[i - 1], hipEventDisableTiming));
     }
     BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_last, hipEventDisableTiming));
+    for (auto& sl : ctx->io) {
+        BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+        BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming));
+    }
     BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming));
     BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_vfork, hipEventDisableTiming));
     BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_vjoin, hipEventDisableTiming));
@@ -220,6 +224,14 @@ extern "C" void bbp_free(bbp_ctx* ctx) {
         delete c;
     }
     ctx->circuits.clear();
+    for (auto& sl : ctx->io) {
+        for (void* p : {sl.in.p, sl.ent.p, sl.out.p})
+            if (p) (void)hipFree(p);
+        if (sl.h_out) (void)hipHostFree(sl.h_out);
+        if (sl.h_in) (void)hipHostFree(sl.h_in);
+        if (sl.ev) (void)hipEventDestroy(sl.ev);
+        if (sl.ev_in) (void)hipEventDestroy(sl.ev_in);
+    }
     for (auto& kv : ctx->layout_idx)
         if (kv.second) (void)hipFree(kv.second);
     ctx->layout_idx.clear();

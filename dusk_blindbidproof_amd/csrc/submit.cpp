@@ -25,46 +25,77 @@ static bool same_class(const Request* a, const Request* b) {
     return a->kind == b->kind && a->N == b->N && a->rec_ver == b->rec_ver && a->in_len == b->in_len && (a->entropy == nullptr) == (b->entropy == nullptr);
 }
 
+void Combiner::designate_locked() {
+    for (Request* q : q_) {
+        if (leaders_ >= MAX_LEADERS) return;
+        if (!q->lead && !q->leading) {  // a leader in its window still has its own request queued: never designate it twice
+            q->lead = true;
+            leaders_++;
+            q->cv.notify_one();
+        }
+    }
+}
+
 int32_t Combiner::submit(bbp_ctx* ctx, Request& r) {
     std::unique_lock<std::mutex> lk(mu_);
     q_.push_back(&r);
-    if (!leader_active_) {
-        leader_active_ = true;
-        r.lead = true;  // the queue was drained by the previous leader, so r is its head
-    } else {
-        cv_.notify_all();  // a leader sitting in its batching window counts arrivals
-    }
+    designate_locked();
+    cv_window_.notify_one();  // a leader sitting in its batching window counts arrivals
+    auto resign = [&] {       // give the leader slot back and let a queued caller have it
+        r.leading = false;
+        leaders_--;
+        designate_locked();
+    };
     for (;;) {
-        cv_.wait(lk, [&] { return r.done || r.lead; });
-        if (r.done) return r.status;
-        // leader: r is the head of the queue.  Optional window: give concurrent callers a moment to join this batch.
+        r.cv.wait(lk, [&] { return r.done || r.lead; });
+        if (!r.lead) return r.status;  // done, and not holding a leader slot
+        r.lead = false;
+        r.leading = true;
+        if (r.done || q_.empty()) {  // nothing (left) for this leader to run
+            resign();
+            if (r.done) return r.status;
+            continue;  // r is inside another leader's batch: wait for it
+        }
+        // Optional window: give concurrent callers a moment to join this batch.
         if (window_us_) {
             const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(window_us_);
-            while (q_.size() < max_batch_ && cv_.wait_until(lk, deadline) != std::cv_status::timeout) {
+            while (q_.size() < max_batch_ && cv_window_.wait_until(lk, deadline) != std::cv_status::timeout) {
+            }
+            if (q_.empty()) {  // the other leader took everything meanwhile
+                resign();
+                if (r.done) return r.status;
+                continue;
             }
         }
+        // one batch from the head of the queue: everything of the head's class, in arrival order (r itself is usually in it)
+        const Request* head = q_.front();
         std::vector<Request*> batch;
         for (auto it = q_.begin(); it != q_.end() && batch.size() < max_batch_;) {
-            if (same_class(*it, &r)) {
+            if (same_class(*it, head)) {
                 batch.push_back(*it);
                 it = q_.erase(it);
             } else {
                 ++it;
             }
         }
+        for (Request* b : batch)
+            if (b->lead) {  // designated but not yet awake, and now inside this batch: it will find nothing to lead
+                b->lead = false;
+                leaders_--;
+            }
         lk.unlock();
-        run_batch(ctx, batch);  // r is in it
+        run_batch(ctx, batch);
         lk.lock();
         n_calls_++;
         n_requests_ += batch.size();
         if (batch.size() > max_seen_) max_seen_ = (uint32_t)batch.size();
-        for (Request* b : batch) b->done = true;
-        r.lead = false;
-        if (q_.empty())
-            leader_active_ = false;
-        else
-            q_.front()->lead = true;  // hand over: nobody serves other callers for longer than one batch
-        cv_.notify_all();
+        for (Request* b : batch) {
+            b->done = true;
+            if (b != &r) b->cv.notify_one();
+        }
+        resign();  // nobody serves other callers for longer than one batch
+        if (r.done && !r.lead) return r.status;
+        // (r.lead again: resign() found r still queued -- a different class than the batch it just ran -- and picked it)
     }
 }
 

@@ -5,8 +5,10 @@
 // efficiency is the batch, so bbp_prove / bbp_verify (and through them the UDS server under server/) hand their request to this
 // queue: the first caller to find the engine free becomes the leader, takes every queued request of its class (same kind, list
 // length, record layout, entropy mode), runs ONE bbp_prove_batch / bbp_verify_batch under the context lock and distributes the
-// results; requests that arrive while a batch is on the device form the next batch.  Leadership is handed to the head of the
-// queue after every batch, so no caller serves others for longer than one batch.
+// results; requests that arrive while a batch is on the device form the next batch.  Up to TWO batches are in flight at a time
+// (two leaders): the host-pointer batch calls hold the context lock only while they enqueue, so the second batch's host work and
+// its opening stage on the device run under the first batch's MSM stage -- the engine's cross-call pipeline, kept full by the
+// queue.  A leader runs ONE batch taken from the head of the queue, then leadership goes to a waiting caller.
 #pragma once
 #include <stdint.h>
 
@@ -30,7 +32,10 @@ struct Request {
     uint8_t* out = nullptr;          // prove only: bbp_proof_record_size(N) bytes
     int32_t status = 6;              // BBP_ERR_INTERNAL until the batch has run
     std::string err;
-    bool done = false, lead = false;
+    bool done = false;
+    bool lead = false;     // designated to run a batch, not yet acknowledged
+    bool leading = false;  // acting as a leader right now (its own request may still sit in the queue during the window)
+    std::condition_variable cv;      // each waiter has its own: a finished batch wakes its members, not every queued caller
 };
 
 // what a combined call runs (capi_prove.hip); both take the context lock themselves
@@ -47,9 +52,11 @@ class Combiner {
   private:
     void run_batch(bbp_ctx* ctx, std::vector<Request*>& batch);
     std::mutex mu_;
-    std::condition_variable cv_;
+    std::condition_variable cv_window_;  // arrivals -> the leader that sits in its batching window
     std::deque<Request*> q_;
-    bool leader_active_ = false;
+    static constexpr int MAX_LEADERS = 2;
+    int leaders_ = 0;         // callers currently designated to run (or running) a batch
+    void designate_locked();  // hand free leader slots to queued callers
     uint32_t window_us_ = 0, max_batch_ = 4096;
     uint64_t n_calls_ = 0, n_requests_ = 0;
     uint32_t max_seen_ = 0;

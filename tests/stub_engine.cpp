@@ -14,6 +14,17 @@
 struct bbp_ctx {
     bbp::Combiner combiner;
     std::atomic<uint64_t> batch_calls{0};
+    std::atomic<int> inside{0}, max_inside{0};  // combined calls running at the same time (the combiner allows two)
+};
+struct Inside {
+    bbp_ctx* c;
+    explicit Inside(bbp_ctx* ctx) : c(ctx) {
+        const int n = ++c->inside;
+        int m = c->max_inside.load();
+        while (n > m && !c->max_inside.compare_exchange_weak(m, n)) {
+        }
+    }
+    ~Inside() { --c->inside; }
 };
 
 static thread_local std::string t_err;
@@ -31,6 +42,7 @@ static bool canonical(const uint8_t* s) {  // < 2^253 is enough for a stub: the 
 namespace bbp {
 int32_t prove_batch_locked(bbp_ctx* ctx, uint32_t B, uint32_t N, const uint8_t* in, const uint8_t*, uint8_t* out, int32_t* status, std::string*) {
     ctx->batch_calls++;
+    Inside in_call(ctx);
     usleep(3000);  // one "device call" costs the same whatever B is: combining is what pays
     const size_t in_stride = 7 * 32 + 32 * (size_t)N + 8, rec = 1121 + 32 * (4 + (size_t)N);
     for (uint32_t i = 0; i < B; i++) {
@@ -52,6 +64,7 @@ int32_t prove_batch_locked(bbp_ctx* ctx, uint32_t B, uint32_t N, const uint8_t* 
 }
 int32_t verify_batch_locked(bbp_ctx* ctx, uint32_t B, uint32_t N, uint32_t rec_ver, const uint8_t* in, int32_t* status, std::string*) {
     ctx->batch_calls++;
+    Inside in_call(ctx);
     usleep(1000);
     const size_t rec = (rec_ver ? 1217 : 1121) + 32 * (4 + (size_t)N), stride = rec + 96 + 32 * (size_t)N;
     for (uint32_t i = 0; i < B; i++) {
@@ -81,6 +94,7 @@ int32_t bbp_batching_stats(bbp_ctx* c, uint64_t* a, uint64_t* b, uint32_t* m) {
     c->combiner.stats(a, b, m);
     return BBP_OK;
 }
+int32_t stub_max_concurrency(bbp_ctx* c) { return c->max_inside.load(); }
 int32_t bbp_prove(bbp_ctx* c, const uint8_t s7[7 * 32], const uint8_t* pub, uint32_t N, uint64_t toggle, const uint8_t* ent, uint8_t* out,
                   uint32_t* plen) {
     if (N == 0) return BBP_ERR_BAD_ARG;

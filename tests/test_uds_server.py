@@ -142,6 +142,48 @@ def test_concurrent_connections_are_micro_batched(server):
     assert served >= 2 * T * per and calls < served // 2 and biggest >= 4, m.group(0)
 
 
+def test_combiner_keeps_two_batches_in_flight(built):
+    """The call combiner (csrc/submit.cpp, the product's own code behind the stub) lets TWO combined calls run at once -- what
+    keeps the engine's cross-call pipeline full -- never more, loses no request, and bounds every batch by max_batch."""
+    import ctypes
+    L = ctypes.CDLL(built.build_stub_engine())
+    h = ctypes.c_void_p()
+    L.bbp_init.argtypes = [ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)]
+    assert L.bbp_init(0, ctypes.byref(h)) == 0
+    L.bbp_set_batching.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32]
+    L.bbp_set_batching(h, 100, 8)
+    L.bbp_prove.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    L.bbp_verify.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
+    L.stub_max_concurrency.argtypes = [ctypes.c_void_p]
+    T, per, errors = 48, 6, []
+
+    def worker(t):
+        try:
+            for j in range(per):
+                n = 2 + (t + j) % 3                                        # three list lengths = three request classes in the queue
+                s7, pub, toggle = _bid(t * per + j, n)
+                out = (ctypes.c_uint8 * (1121 + 32 * (4 + n)))()
+                assert L.bbp_prove(h, s7, pub, n, toggle, None, out, None) == 0
+                assert L.bbp_verify(h, bytes(out), len(out), s7[128:160], s7[160:192], s7[192:224], pub, n) == 0
+                bad = bytearray(bytes(out))
+                bad[7] ^= 1
+                assert L.bbp_verify(h, bytes(bad), len(out), s7[128:160], s7[160:192], s7[192:224], pub, n) == 1
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errors, errors[:3]
+    calls, reqs, biggest = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint32()
+    L.bbp_batching_stats.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 3
+    L.bbp_batching_stats(h, ctypes.byref(calls), ctypes.byref(reqs), ctypes.byref(biggest))
+    assert reqs.value == T * per * 3 and biggest.value <= 8 and calls.value < reqs.value
+    assert L.stub_max_concurrency(h) == 2
+
+
 def test_cli_mirrors_the_reference_flags(built):
     built.build_server()
     p = subprocess.run([built.SERVER_BIN, "-l", "loud"], capture_output=True, text=True)

@@ -66,6 +66,9 @@ def main():
     srv.send_signal(signal.SIGTERM)
     srv.wait(timeout=30)
     log.seek(0)
+    if os.environ.get("BBP_TRACE"):
+        sys.stderr.write("".join([ln for ln in log.read().splitlines(True) if "trace" in ln][-40:]))
+        log.seek(0)
     m = re.search(r"served (\d+) requests \((\d+) errors\) in (\d+) device calls, largest batch (\d+)", log.read())
     out = json.loads(run.stdout.strip().splitlines()[-1]) if run.stdout.strip() else {"error": run.stderr[-300:], "warmup": warm.stderr[-300:]}
     out.update(workload="configs[4] through the UDS server: closed-loop prove+verify per connection", bid_list_len=N, window_us=a.window_us,
