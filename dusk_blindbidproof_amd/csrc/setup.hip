@@ -131,6 +131,10 @@ static int32_t init_body(int32_t device, bbp_ctx** out) {
     *out = ctx;  // returned even on failure so bbp_last_error works; caller frees
     ctx->combiner = new Combiner();
     if (const char* e = getenv("BBP_BATCH_WINDOW_US")) static_cast<Combiner*>(ctx->combiner)->configure((uint32_t)atoi(e), 0);
+    {  // the prover's opening stage lasts ~36 ms whatever the batch size: a second batch starts no earlier
+        const char* e = getenv("BBP_BATCH_STAGGER_US");
+        static_cast<Combiner*>(ctx->combiner)->set_stagger(e ? (uint32_t)atoi(e) : 35000u);
+    }
     BBP_HIP_TRY(ctx, hipSetDevice(device));
     hipDeviceProp_t prop;
     BBP_HIP_TRY(ctx, hipGetDeviceProperties(&prop, device));

@@ -14,6 +14,11 @@ void Combiner::configure(uint32_t window_us, uint32_t max_batch) {
     max_batch_ = max_batch ? max_batch : 4096;
 }
 
+void Combiner::set_stagger(uint32_t us) {
+    std::lock_guard<std::mutex> lk(mu_);
+    stagger_us_ = us;
+}
+
 void Combiner::stats(uint64_t* n_calls, uint64_t* n_requests, uint32_t* max_seen) {
     std::lock_guard<std::mutex> lk(mu_);
     if (n_calls) *n_calls = n_calls_;
@@ -67,6 +72,17 @@ int32_t Combiner::submit(bbp_ctx* ctx, Request& r) {
                 continue;
             }
         }
+        if (stagger_us_ && inflight_ > 0 && q_.front()->kind == 0) {  // a PROVE batch is on the device and this would be another:
+            // let it grow until that one's opening stage is over (verifications have no such stage and never wait here)
+            const auto start_at = last_start_ + std::chrono::microseconds(stagger_us_);
+            while (inflight_ > 0 && q_.size() < max_batch_ && cv_window_.wait_until(lk, start_at) != std::cv_status::timeout) {
+            }
+            if (q_.empty()) {
+                resign();
+                if (r.done) return r.status;
+                continue;
+            }
+        }
         // one batch from the head of the queue: everything of the head's class, in arrival order (r itself is usually in it)
         const Request* head = q_.front();
         std::vector<Request*> batch;
@@ -83,9 +99,16 @@ int32_t Combiner::submit(bbp_ctx* ctx, Request& r) {
                 b->lead = false;
                 leaders_--;
             }
+        const bool proving = batch[0]->kind == 0;  // inflight_ / last_start_ track prove batches only
+        if (proving) {
+            inflight_++;
+            last_start_ = std::chrono::steady_clock::now();
+        }
         lk.unlock();
         run_batch(ctx, batch);
         lk.lock();
+        if (proving) inflight_--;
+        cv_window_.notify_all();  // a leader holding back behind this batch may go now
         n_calls_++;
         n_requests_ += batch.size();
         if (batch.size() > max_seen_) max_seen_ = (uint32_t)batch.size();

@@ -12,6 +12,7 @@
 #pragma once
 #include <stdint.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
@@ -47,6 +48,10 @@ class Combiner {
   public:
     int32_t submit(bbp_ctx* ctx, Request& r);
     void configure(uint32_t window_us, uint32_t max_batch);
+    // A leader that finds another batch in flight does not start before `us` after that batch STARTED: for the prover this is
+    // the length of the opening stage (the next batch's opening cannot begin earlier anyway), and meanwhile the batch grows --
+    // without it a few hundred closed-loop callers fragment into many small batches that each pay the full latency floor.
+    void set_stagger(uint32_t us);
     void stats(uint64_t* n_calls, uint64_t* n_requests, uint32_t* max_seen);
 
   private:
@@ -57,7 +62,9 @@ class Combiner {
     static constexpr int MAX_LEADERS = 2;
     int leaders_ = 0;         // callers currently designated to run (or running) a batch
     void designate_locked();  // hand free leader slots to queued callers
-    uint32_t window_us_ = 0, max_batch_ = 4096;
+    uint32_t window_us_ = 0, max_batch_ = 4096, stagger_us_ = 0;
+    int inflight_ = 0;
+    std::chrono::steady_clock::time_point last_start_{};
     uint64_t n_calls_ = 0, n_requests_ = 0;
     uint32_t max_seen_ = 0;
 };
