@@ -84,7 +84,8 @@ def roofline(wl, timings, steps, alu_peak=None, wall_s=None):
     # (the engine may cut a batch into slices on several streams, multiplying the launch count)
     alg_per_launch = wl.alg_bytes_per_step * steps / max(len(dom), 1)
     achieved = alg_per_launch / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
-    traffic, traffic_src = wl.measured_traffic()
+    traffic_step, traffic_src = wl.measured_traffic()  # per step, from the named profile; per launch = spread over what this run launched
+    traffic = traffic_step * steps / max(len(dom), 1) if traffic_step else None
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
            "traffic": traffic, "traffic_source": traffic_src, "kernel": wl.dominant_kernel, "avg_launch_us": avg_us, "launches": len(dom),
            "alg_bytes_per_launch": alg_per_launch,
@@ -92,7 +93,7 @@ def roofline(wl, timings, steps, alu_peak=None, wall_s=None):
                    "avg_launch_us is co-residency-stretched when slices overlap -- the exclusive figure is in the named profile"}
     if traffic and wall_s and dom:
         # measured HBM-side bytes of the dominant kernel over the WALL time of the region (launches x traffic per launch)
-        out["hbm_side_GBps_whole_step"] = traffic * len(dom) / wall_s / 1e9
+        out["hbm_side_GBps_whole_step"] = traffic_step * steps / wall_s / 1e9
     if alu_peak:
         # secondary, honest roofline (SURVEY.md 7 hard part 2): table-row additions the MSM kernels actually perform per second
         # (one per non-zero NAF digit) against the register-resident mixed-addition rate bbp_ubench measures live (no memory traffic)

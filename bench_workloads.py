@@ -80,14 +80,14 @@ MERGED_AI_TERMS = 4 * 90 * 4  # A_I1 terms that ride on another term's merged ba
 
 
 def _traffic_from_profiles(key):
-    """HBM bytes per dominant-kernel launch as MEASURED by the rocprofv3 PMC passes of the named profile (FETCH_SIZE and
+    """HBM-side bytes of the dominant kernel per STEP (one batch) as MEASURED by the rocprofv3 PMC passes of the named profile (FETCH_SIZE and
     WRITE_SIZE in separate runs; FETCH_SIZE x 2 on gfx950 per MI355X_MICROARCH.md's HBM section).  The figure is read from
     profiles/traffic.json, which tools/pmc_aggregate.py writes from the counter CSVs -- not measured in this run, so the bench
     line names the file it comes from; (None, None) when there is no profile of this workload."""
     try:
         import json
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[key]
-        return int(t["bytes_per_launch"]), t["source"]
+        return int(t["bytes_per_step"]), t["source"]
     except Exception:
         return None, None
 

@@ -34,5 +34,5 @@ def test_measured_traffic_comes_from_a_named_profile():
     passes by tools/pmc_aggregate.py) together with the name of the profile it came from, or it is null."""
     import os
     t, src = bw._traffic_from_profiles("prove_b1024_n8")
-    assert t is None or (1e8 < t < 2e10 and src.startswith("profiles/") and os.path.exists(os.path.join(bw.ROOT, src.split(" ")[0])))
+    assert t is None or (1e9 < t < 1e12 and src.startswith("profiles/") and os.path.exists(os.path.join(bw.ROOT, src.split(" ")[0])))
     assert bw._traffic_from_profiles("no such workload") == (None, None)
