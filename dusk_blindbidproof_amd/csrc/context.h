@@ -78,6 +78,14 @@ struct bbp_ctx {
     int slices = 3;
     int tail_round = bbp::FOLD_ROUND;  // first IPA round run on explicit folded generators (BBP_TAIL_ROUND=12 disables)
     int serial_lds = 160 * 1024;  // LDS the one-lane-per-proof opening kernels reserve to keep their CU to themselves (BBP_SERIAL_LDS, 0 = off)
+    // TranscriptRng draw chain on 25 lanes per sponge (k_open_bulk) instead of one lane per proof.  The cooperative form is bound
+    // by the CU's LDS crossbar (18 ds_bpermute per round): with ONE wavefront (two proofs) per CU a permutation takes a third of
+    // the single-lane time -- a single proof 44 -> 25 ms, 256 proofs 55 -> 41 ms -- but 1024 proofs would need 512 CUs' worth of
+    // crossbar, and the single-lane chain hides under the previous batch's MSM stage anyway.  Auto (-1): cooperative for batches
+    // of at most rng_coop_below proofs.  BBP_RNG_COOP=0 / 1 forces, BBP_RNG_COOP_BELOW, BBP_RNG_BLOCK tune.
+    int rng_coop = -1;
+    int rng_coop_below = 256;
+    int rng_block = 64;           // threads per workgroup of k_open_bulk: 64 = one wavefront (two proofs) per reserved CU
     int serial_block = 64;        // threads per workgroup of those kernels: 256 = one serial wave per SIMD of the reserved CU (BBP_SERIAL_BLOCK)
     std::map<const void*, int> serial_attr;
     int stagger_mode = 0;  // 0: slices start together, 1: next slice starts after this slice's first MSM, 3: after its third (BBP_STAGGER)

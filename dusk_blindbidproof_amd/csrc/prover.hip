@@ -228,7 +228,7 @@ __device__ __forceinline__ u32 enc_stride_words(u32 m) { return (m + 8 + 22) * 8
 
 __device__ void tr_open_lane(u32 p, u32 m, u32 n1, const merlin_transcript& prefix, const u32* __restrict__ enc, const u8* __restrict__ entropy,
                              const sc* __restrict__ vb_all, u32* __restrict__ raw, merlin_transcript* __restrict__ tr_out,
-                             merlin_transcript* __restrict__ rng_out) {
+                             merlin_transcript* __restrict__ rng_out, bool coop) {
     merlin_transcript t = prefix;  // Transcript::new(b"BlindBidProofGadget") + r1cs_domain_sep (A.4)
     const u32* e = enc + (size_t)p * enc_stride_words(m);
     for (u32 i = 0; i < m; i++) tr_append_words(t, LBL("V"), e + 8 * i);
@@ -253,7 +253,8 @@ __device__ void tr_open_lane(u32 p, u32 m, u32 n1, const merlin_transcript& pref
         merlin_rng_fill(r, b, 64);  // first draw leaves the sponge in the steady state the bulk path needs
         bytes_to_words(rw, b, 16);
     }
-    merlin_rng_fill64_bulk(r, 2 + 2 * n1, rw + 16);
+    // the remaining 2 + 2 n1 draws: BBP_RNG_COOP (default) leaves them to the cooperative kernel (k_open_bulk, 25 lanes per sponge)
+    if (!coop) merlin_rng_fill64_bulk(r, 2 + 2 * n1, rw + 16);
     tr_out[p] = t;
     rng_out[p] = r;
 }
@@ -261,18 +262,118 @@ __device__ void tr_open_lane(u32 p, u32 m, u32 n1, const merlin_transcript& pref
 // The two strictly serial jobs of the opening stage in ONE launch: the first `rng_blocks` workgroups run the transcript opening +
 // the 2935 sequential rng draws of their proofs, the others interpret the gadget program of theirs.  Neither needs the other
 // (the V commitments only need k_witness_head), so the opening stage lasts max(36 ms, 6 ms) instead of their sum.
+// (BBP_RNG_COOP=0 path: one lane per proof does everything.  Default path: this kernel is launched with rng lanes only for the
+// transcript prefix -- V x m, "m", rng rekeys, first draw -- and k_open_bulk does the bulk of the draws and the witness.)
 __global__ void k_open_serial(u32 B, u32 rng_blocks, u32 m, u32 n1, merlin_transcript prefix, const u32* __restrict__ enc,
                               const u8* __restrict__ entropy, const sc* __restrict__ vb_all, u32* __restrict__ raw,
                               merlin_transcript* __restrict__ tr_out, merlin_transcript* __restrict__ rng_out, u32 n_cst,
                               const u32* __restrict__ w_terms, const u32* __restrict__ w_loff, const u32* __restrict__ w_roff,
-                              const sc* __restrict__ cst_all, const sc* __restrict__ v_all, sc* __restrict__ ai1_all, sc* __restrict__ ao1_all) {
+                              const sc* __restrict__ cst_all, const sc* __restrict__ v_all, sc* __restrict__ ai1_all, sc* __restrict__ ao1_all,
+                              u32 coop) {
     if (blockIdx.x < rng_blocks) {
         const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
-        if (p < B) tr_open_lane(p, m, n1, prefix, enc, entropy, vb_all, raw, tr_out, rng_out);
+        if (p < B) tr_open_lane(p, m, n1, prefix, enc, entropy, vb_all, raw, tr_out, rng_out, coop != 0);
     } else {
         const u32 p = (blockIdx.x - rng_blocks) * blockDim.x + threadIdx.x;
         if (p < B) witness_gates_lane(p, m, n1, n_cst, w_terms, w_loff, w_roff, cst_all, v_all, ai1_all, ao1_all);
     }
+}
+
+// ---- cooperative Keccak: the TranscriptRng draw chain with 25 lanes per sponge --------------------------------------------------
+// A proof's 2 + 2 n1 (= 2934 at N = 8) steady-state draws are strictly sequential -- each is one Keccak-f[1600] of the previous
+// state (keccak.h merlin_rng_fill64_bulk) -- so one lane per proof runs 2934 x 24 rounds x ~270 dependent-ish instructions: 36 ms
+// whatever the batch size, the floor under every small batch and under a single proof's latency.  Here a sponge is spread over a
+// 32-lane group (lane i < 25 holds state word i = x + 5y as a register pair; two groups per wavefront): theta's column parities,
+// the neighbours for D, and the fused rho-pi-chi gather are cross-lane reads (ds_bpermute: 18 per round), everything else is
+// per-lane 64-bit arithmetic with lane-constant rotation counts -- ~50 instructions per round per wavefront instead of ~270,
+// in three short dependent phases.  The bytes are the same (tests compare every record with the oracle).
+__device__ __forceinline__ u64 coop_gather64(int addr, u64 v) {
+    const u32 lo = (u32)__builtin_amdgcn_ds_bpermute(addr, (int)(u32)v);
+    const u32 hi = (u32)__builtin_amdgcn_ds_bpermute(addr, (int)(u32)(v >> 32));
+    return ((u64)hi << 32) | lo;
+}
+
+struct coop_lane {  // per-lane constants of the cooperative permutation
+    int col[4], dm, dp, s0, s1, s2;  // byte addresses (4 * source lane) for ds_bpermute
+    u32 rot;                         // rho offset of THIS lane's word
+    u64 iota_mask;                   // all ones in lane 0 of the group
+};
+
+__device__ __forceinline__ coop_lane coop_setup(u32 lane_in_wave) {
+    const u32 l = lane_in_wave & 31u, base = lane_in_wave & 32u;
+    const u32 li = l < 25 ? l : 0;  // idle lanes mirror lane 0's wiring; their values are never read by live lanes
+    const u32 x = li % 5, y = li / 5;
+    const u32 RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+    coop_lane c;
+#pragma unroll
+    for (int k = 0; k < 4; k++) c.col[k] = 4 * (int)(base + x + 5 * ((y + 1 + k) % 5));
+    c.dm = 4 * (int)(base + (x + 4) % 5 + 5 * y);
+    c.dp = 4 * (int)(base + (x + 1) % 5 + 5 * y);
+    // rho-pi-chi fused: destination (X, Y) needs B[X][Y], B[X+1][Y], B[X+2][Y]; B[X][Y] is the rotated word of source lane
+    // ((X + 3Y) mod 5) + 5 X   (pi: B[y][2x+3y] = rot(A[x][y]))
+    auto src = [&](u32 X) { return 4 * (int)(base + (X + 3 * y) % 5 + 5 * X); };
+    c.s0 = src(x);
+    c.s1 = src((x + 1) % 5);
+    c.s2 = src((x + 2) % 5);
+    c.rot = RHO[li];
+    c.iota_mask = l == 0 ? ~0ull : 0ull;
+    return c;
+}
+
+__device__ __forceinline__ u64 coop_keccak_f(u64 a, const coop_lane& c) {
+    const u64 RC[24] = {0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808Aull, 0x8000000080008000ull,
+                        0x000000000000808Bull, 0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull,
+                        0x000000000000008Aull, 0x0000000000000088ull, 0x0000000080008009ull, 0x000000008000000Aull,
+                        0x000000008000808Bull, 0x800000000000008Bull, 0x8000000000008089ull, 0x8000000000008003ull,
+                        0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800Aull, 0x800000008000000Aull,
+                        0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+#pragma unroll 1
+    for (int r = 0; r < 24; r++) {
+        // theta: C[x] in every lane of column x, then D[x] = C[x-1] ^ rotl(C[x+1], 1)
+        const u64 C = a ^ coop_gather64(c.col[0], a) ^ coop_gather64(c.col[1], a) ^ coop_gather64(c.col[2], a) ^ coop_gather64(c.col[3], a);
+        const u64 Cm = coop_gather64(c.dm, C), Cp = coop_gather64(c.dp, C);
+        a ^= Cm ^ ((Cp << 1) | (Cp >> 63));
+        // rho at the source, then pi and chi's two neighbours in one gather phase
+        const u64 ro = (a << c.rot) | (a >> ((64u - c.rot) & 63u));
+        const u64 b0 = coop_gather64(c.s0, ro), b1 = coop_gather64(c.s1, ro), b2 = coop_gather64(c.s2, ro);
+        a = b0 ^ (~b1 & b2);
+        a ^= RC[r] & c.iota_mask;  // iota
+    }
+    return a;
+}
+
+// rng lanes: (B proofs) x 32 lanes, two proofs per wavefront; witness lanes (blocks >= rng_blocks): one lane per proof as before
+__global__ void k_open_bulk(u32 B, u32 rng_blocks, u32 n1, u32 count, merlin_transcript* __restrict__ rng, u32* __restrict__ raw, u32 m,
+                            u32 n_cst, const u32* __restrict__ w_terms, const u32* __restrict__ w_loff, const u32* __restrict__ w_roff,
+                            const sc* __restrict__ cst_all, const sc* __restrict__ v_all, sc* __restrict__ ai1_all, sc* __restrict__ ao1_all) {
+    if (blockIdx.x >= rng_blocks) {
+        const u32 p = (blockIdx.x - rng_blocks) * blockDim.x + threadIdx.x;
+        if (p < B) witness_gates_lane(p, m, n1, n_cst, w_terms, w_loff, w_roff, cst_all, v_all, ai1_all, ao1_all);
+        return;
+    }
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 g = t >> 5, l = t & 31u;
+    const bool live = g < B && l < 25;
+    const u32 p = g < B ? g : B - 1;
+    const coop_lane c = coop_setup(threadIdx.x & 63u);
+    merlin_transcript* T = rng + p;
+    u64 a = live ? T->st[l] : 0;
+    // per-draw constants (keccak.h merlin_rng_fill64_bulk): st[8] ^= .., st[9] ^= .., st[20] ^= ..
+    const u64 konst = l == 8 ? 0x0741000000401200ull : l == 9 ? 0x0000000000000447ull : l == 20 ? 0x8000000000000000ull : 0ull;
+    u32* out = raw + (size_t)p * (3 + 2 * (size_t)n1) * 16 + 16 + 2 * l;  // draw 0 was written by the prefix kernel
+    for (u32 d = 0; d < count; d++) {
+        a ^= konst;
+        a = coop_keccak_f(a, c);
+        if (l < 8) {
+            if (live) {
+                out[(size_t)d * 16] = (u32)a;
+                out[(size_t)d * 16 + 1] = (u32)(a >> 32);
+            }
+            a = 0;
+        }
+    }
+    if (live) T->st[l] = a;
+    if (live && l == 0) T->cur_flags = BBP_FLAG_I | BBP_FLAG_A | BBP_FLAG_C;
 }
 
 // draw j of proof p -> its scalar slot: 0 -> ai1[0], 1 -> ao1[0], 2 -> s1[0], j >= 3 -> s1[1 + (j - 3)]
@@ -1121,8 +1222,22 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
         LAUNCH(ctx, TAG_TRANSCRIPT, k_load_blindings, cdiv(B * m, 64), 64, s, B, m, ent_dev, bd.vb);
         if ((rc = commit_launch(ctx, B * m, bd.v, bd.vb, m, m, m, bd.pts, m + 8, s))) return rc;
         LAUNCH(ctx, TAG_ENCODE, k_encode_strided, cdiv(B * m, 64), 64, s, B * m, m, bd.pts, m + 8, bd.enc, encw, 0u);
-        LAUNCH_LDS(ctx, TAG_RNG, k_open_serial, 2 * cdiv(B, sblk), sblk, hog, s, B, cdiv(B, sblk), m, n1, prefix, bd.enc, ent_dev, bd.vb,
-                   (u32*)ctx->raw[sidx].p, bd.tr, bd.rng, c.n_cst, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v, bd.ai1, bd.ao1);
+        const bool coop = ctx->rng_coop < 0 ? B <= (u32)ctx->rng_coop_below : ctx->rng_coop != 0;
+        if (!coop) {
+            LAUNCH_LDS(ctx, TAG_RNG, k_open_serial, 2 * cdiv(B, sblk), sblk, hog, s, B, cdiv(B, sblk), m, n1, prefix, bd.enc, ent_dev, bd.vb,
+                       (u32*)ctx->raw[sidx].p, bd.tr, bd.rng, c.n_cst, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v, bd.ai1, bd.ao1, 0u);
+        } else {
+            // prefix: one lane per proof, ~20 permutations (V x m, "m", the rng's rekeys, the first draw): 0.3 ms, no witness blocks
+            LAUNCH(ctx, TAG_RNG, k_open_serial, cdiv(B, 64), 64, s, B, cdiv(B, 64), m, n1, prefix, bd.enc, ent_dev, bd.vb, (u32*)ctx->raw[sidx].p,
+                   bd.tr, bd.rng, c.n_cst, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v, bd.ai1, bd.ao1, 1u);
+            // bulk: 32 lanes per proof for the draw chain + one lane per proof for the witness, in one launch of `cblk`-thread
+            // workgroups that keep their CU to themselves (LDS hog): cblk / 32 proofs per rng workgroup
+            if ((rc = serial_lds_bytes(ctx, (const void*)k_open_bulk))) return rc;
+            const u32 cblk = (u32)ctx->rng_block;
+            const u32 nb_rng = cdiv(B * 32, cblk), nb_wit = cdiv(B, cblk);
+            LAUNCH_LDS(ctx, TAG_RNG, k_open_bulk, nb_rng + nb_wit, cblk, hog, s, B, nb_rng, n1, 2 + 2 * n1, bd.rng, (u32*)ctx->raw[sidx].p, m,
+                       c.n_cst, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v, bd.ai1, bd.ao1);
+        }
         LAUNCH(ctx, TAG_RNG, k_reduce_draws, cdiv((u32)(B * n_draws), 128), 128, s, B, n1, (const u32*)ctx->raw[sidx].p, bd.ai1, bd.ao1, bd.s1);
         BBP_HIP_TRY(ctx, hipEventRecord(ctx->ev_open[par], s));
         ctx->ev_open_valid[par] = true;

@@ -163,6 +163,12 @@ static int32_t init_body(int32_t device, bbp_ctx** out) {
     if (const char* e = getenv("BBP_VARBASE_LANES")) ctx->varbase_lanes = atoi(e) < 64 ? 64 : atoi(e);
     if (const char* e = getenv("BBP_TAIL_ROUND")) ctx->tail_round = atoi(e) == bbp::FOLD_ROUND ? bbp::FOLD_ROUND : 12;
     if (const char* e = getenv("BBP_STAGGER")) ctx->stagger_mode = atoi(e);
+    if (const char* e = getenv("BBP_RNG_COOP")) ctx->rng_coop = atoi(e) != 0;
+    if (const char* e = getenv("BBP_RNG_COOP_BELOW")) ctx->rng_coop_below = atoi(e);
+    if (const char* e = getenv("BBP_RNG_BLOCK")) {
+        const int v = atoi(e);
+        ctx->rng_block = v >= 1024 ? 1024 : v >= 512 ? 512 : v >= 256 ? 256 : v >= 128 ? 128 : 64;
+    }
     if (const char* e = getenv("BBP_SERIAL_BLOCK")) ctx->serial_block = atoi(e) == 64 ? 64 : atoi(e) == 128 ? 128 : 256;
     if (const char* e = getenv("BBP_SERIAL_LDS")) ctx->serial_lds = atoi(e) < 0 ? 0 : atoi(e) > 160 * 1024 ? 160 * 1024 : atoi(e);
     if (const char* e = getenv("BBP_SLICES")) ctx->slices = atoi(e) < 1 ? 1 : atoi(e) > bbp_ctx::MAX_SLICES ? bbp_ctx::MAX_SLICES : atoi(e);
