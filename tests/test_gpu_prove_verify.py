@@ -382,8 +382,8 @@ def test_calls_from_different_streams_are_serialised(ctx, oc, bbp):
     {"BBP_VARBASE_LANES": "1000", "BBP_DUAL_OPEN_BELOW": "0"},  # verifier: 3 lanes per proof, ~15 points per lane on one doubling chain
     {"BBP_VARBASE_LANES": "64", "BBP_VERIFY_OVERLAP": "0"},     # verifier: one lane per proof, variable-base kernel in line
     {"BBP_RNG_COOP": "0"},                                      # TranscriptRng draw chain on one lane per proof (round-1 path)
-    {"BBP_RNG_BLOCK": "64", "BBP_SERIAL_LDS": "0"},             # cooperative rng: one wavefront (two proofs) per workgroup, not fenced
-    {"BBP_RNG_BLOCK": "1024"},                                  # cooperative rng: 32 proofs per reserved CU
+    {"BBP_RNG_COOP": "1", "BBP_RNG_BLOCK": "64", "BBP_SERIAL_LDS": "0"},  # cooperative rng forced: one wavefront (two proofs) per workgroup, not fenced
+    {"BBP_RNG_COOP": "1", "BBP_RNG_BLOCK": "1024"},             # cooperative rng forced: 32 proofs per reserved CU
 ])
 def test_engine_schedules_give_identical_bytes(bbp, oc, knobs):
     """The scheduling knobs (slices, tail round, serial-kernel fencing, stagger) change WHEN and HOW work runs, never the bytes:
