@@ -298,6 +298,13 @@ def main():
             out["cpu_baseline"] = dict(wl.cpu_baseline(), cpu_model=cpu_model())
         print(json.dumps(out), flush=True)
     if ctx is not None:
+        # torch objects that wrap the context's streams (ExternalStream, events recorded on them) must go before bbp_free destroys
+        # the streams: an event destructor touching a destroyed stream at interpreter exit is a segfault
+        import gc
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(torch.cuda.default_stream())
+        del wl, engine_stream
+        gc.collect()
         ctx.close()
     if world > 1:
         dist.barrier()
