@@ -482,12 +482,12 @@ static int32_t verify_batch_host(bbp_ctx* ctx, uint32_t B, uint32_t N, uint32_t 
             int32_t* cst = (int32_t*)sl.out.p + first;
             if (group > 1) {
                 uint32_t nf = 0;
-                if ((rc = verify_batch_agg_dev(ctx, nb, N, group, cin, cent, cst, ctx->stream, &nf))) return rc;
+                if ((rc = verify_batch_agg_dev(ctx, nb, N, group, cin, cent, cst, ctx->vstream, &nf))) return rc;
                 if (n_fallback) *n_fallback += nf;
-            } else if ((rc = verify_batch_dev_ex(ctx, nb, N, rec_ver, 0, cin, cent, cst, ctx->stream)))
+            } else if ((rc = verify_batch_dev_ex(ctx, nb, N, rec_ver, 0, cin, cent, cst, ctx->vstream)))
                 return rc;
         }
-        BBP_HIP_TRY(ctx, hipEventRecord(sl.ev, ctx->stream));
+        BBP_HIP_TRY(ctx, hipEventRecord(sl.ev, ctx->vstream));
         return BBP_OK;
     });
     if (rc) return rc;

@@ -102,9 +102,13 @@ struct bbp_ctx {
     int last_par = 0;
     // calls on one context share scratch buffers: a call issued on a different caller stream than the previous one is ordered
     // behind it (stream_guard_enter / stream_guard_leave)
-    hipStream_t last_stream = nullptr;
-    hipEvent_t ev_last = nullptr;
-    bool ev_last_valid = false;
+    // two families with disjoint scratch: 0 = prover, MSM hook, witness, setup read-backs; 1 = verifier (its own batch buffer,
+    // misc scratch and MSM scratch slot VERIFY_SLOT) -- a verification issued on another stream than a prove call is NOT ordered
+    // behind it and overlaps its heavy stage on the device
+    hipStream_t last_stream[2] = {nullptr, nullptr};
+    hipEvent_t ev_last[2] = {nullptr, nullptr};
+    bool ev_last_valid[2] = {false, false};
+    hipStream_t vstream = nullptr;  // the host-pointer verify calls run here (prove calls on `stream`)
     std::string err;
     // resident tables
     bbp::ge* gens = nullptr;           // [TAB_BASES] extended points: B_blinding, G[2048], H[2048], B, then the PAD_BASES range sums and the MRG_BASES merged bases
@@ -116,7 +120,8 @@ struct bbp_ctx {
     std::vector<uint8_t> mimc_host;    // 90 * 32
     // grow-only scratch
     bbp::DevBuf scal, idx, sorted, pts, enc, misc, batch[PROVE_BUFS + 1], io_in, io_out, io_ent, raw[2], agg, agg_io;  // batch[3]: the verifier's; raw[i]: draw buffer of opening stream i
-    bbp::DevBuf slice_sorted[MAX_SLICES], slice_pts[MAX_SLICES], slice_fold[MAX_SLICES], slice_vtab[MAX_SLICES];  // per-slice MSM scratch (slice 0 uses sorted / pts)
+    static constexpr int VERIFY_SLOT = MAX_SLICES;  // MSM scratch slot of the verifier
+    bbp::DevBuf slice_sorted[MAX_SLICES + 1], slice_pts[MAX_SLICES + 1], slice_fold[MAX_SLICES], slice_vtab[MAX_SLICES];  // per-slice MSM scratch (slice 0 uses sorted / pts)
     void *agg_vs = nullptr, *agg_varsum = nullptr;  // weighted generator scalars [B][4098] / per-proof variable-base sums of that pass
     int32_t* agg_gstatus = nullptr;  // per-group verdicts of the last aggregated verification (inside agg)
     // Host-pointer batch calls stage through one of two slots (device in / entropy / out + a pinned host mirror of the results):
@@ -209,18 +214,19 @@ inline int32_t serial_lds_bytes(bbp_ctx* ctx, const void* kernel) {
 struct StreamGuard {
     bbp_ctx* ctx;
     hipStream_t s;
+    int fam;  // 0: prover family, 1: verifier family (context.h: disjoint scratch, no ordering between the two)
     bool entered = false;
-    StreamGuard(bbp_ctx* c, hipStream_t st) : ctx(c), s(st) {}
+    StreamGuard(bbp_ctx* c, hipStream_t st, int family = 0) : ctx(c), s(st), fam(family) {}
     int32_t enter() {
-        if (ctx->ev_last_valid && ctx->last_stream != s) BBP_HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_last, 0));
+        if (ctx->ev_last_valid[fam] && ctx->last_stream[fam] != s) BBP_HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_last[fam], 0));
         entered = true;
         return BBP_OK;
     }
     ~StreamGuard() {
         if (!entered) return;
-        if (hipEventRecord(ctx->ev_last, s) == hipSuccess) {
-            ctx->ev_last_valid = true;
-            ctx->last_stream = s;
+        if (hipEventRecord(ctx->ev_last[fam], s) == hipSuccess) {
+            ctx->ev_last_valid[fam] = true;
+            ctx->last_stream[fam] = s;
         }
     }
 };

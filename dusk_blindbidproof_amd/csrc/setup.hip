@@ -153,7 +153,9 @@ static int32_t init_body(int32_t device, bbp_ctx** out) {
     // stage keeps busy (stream, side, lane[1], lane[2]) must not share one (measured: with the copy stream created third, a
     // 1024-proof batch took 60.9 instead of 55.6 ms)
     BBP_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking));
-    BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_last, hipEventDisableTiming));
+    BBP_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->vstream, hipStreamNonBlocking));
+    BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_last[0], hipEventDisableTiming));
+    BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_last[1], hipEventDisableTiming));
     for (auto& sl : ctx->io) {
         BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
         BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming));
@@ -225,7 +227,7 @@ extern "C" void bbp_free(bbp_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     void* ptrs[] = {ctx->gens, ctx->ptable, ctx->btab, ctx->slice_fold[0].p, ctx->slice_fold[1].p, ctx->slice_fold[2].p, ctx->slice_fold[3].p,
-                    ctx->slice_vtab[0].p, ctx->slice_vtab[1].p, ctx->slice_vtab[2].p, ctx->slice_vtab[3].p, ctx->comb, ctx->mimc_c, ctx->scal.p, ctx->idx.p, ctx->sorted.p, ctx->pts.p, ctx->enc.p, ctx->misc.p, ctx->batch[0].p, ctx->io_in.p, ctx->io_out.p, ctx->io_ent.p, ctx->raw[0].p, ctx->raw[1].p, ctx->agg.p, ctx->agg_io.p, ctx->batch[1].p, ctx->batch[2].p, ctx->batch[3].p, ctx->slice_sorted[1].p, ctx->slice_sorted[2].p, ctx->slice_sorted[3].p, ctx->slice_pts[1].p, ctx->slice_pts[2].p, ctx->slice_pts[3].p};
+                    ctx->slice_vtab[0].p, ctx->slice_vtab[1].p, ctx->slice_vtab[2].p, ctx->slice_vtab[3].p, ctx->comb, ctx->mimc_c, ctx->scal.p, ctx->idx.p, ctx->sorted.p, ctx->pts.p, ctx->enc.p, ctx->misc.p, ctx->batch[0].p, ctx->io_in.p, ctx->io_out.p, ctx->io_ent.p, ctx->raw[0].p, ctx->raw[1].p, ctx->agg.p, ctx->agg_io.p, ctx->batch[1].p, ctx->batch[2].p, ctx->batch[3].p, ctx->slice_sorted[1].p, ctx->slice_sorted[2].p, ctx->slice_sorted[3].p, ctx->slice_pts[1].p, ctx->slice_pts[2].p, ctx->slice_pts[3].p, ctx->slice_sorted[4].p, ctx->slice_pts[4].p};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& kv : ctx->circuits) {  // compiled circuits (one per list length used)
@@ -260,7 +262,9 @@ extern "C" void bbp_free(bbp_ctx* ctx) {
         if (ctx->ev_stagger[i - 1]) (void)hipEventDestroy(ctx->ev_stagger[i - 1]);
         if (ctx->lane[i]) (void)hipStreamDestroy(ctx->lane[i]);
     }
-    if (ctx->ev_last) (void)hipEventDestroy(ctx->ev_last);
+    for (int f = 0; f < 2; f++)
+        if (ctx->ev_last[f]) (void)hipEventDestroy(ctx->ev_last[f]);
+    if (ctx->vstream) (void)hipStreamDestroy(ctx->vstream);
     if (ctx->ev_prep) (void)hipEventDestroy(ctx->ev_prep);
     if (ctx->ev_vfork) (void)hipEventDestroy(ctx->ev_vfork);
     if (ctx->ev_vjoin) (void)hipEventDestroy(ctx->ev_vjoin);
