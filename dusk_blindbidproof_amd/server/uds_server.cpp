@@ -32,6 +32,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <vector>
 
 #include "../../include/bbp.h"
 #include "wire.h"
@@ -60,7 +61,11 @@ static void logf(int lvl, const char* fmt, ...) {
 // ---- engine (the C ABI of include/bbp.h, bound at run time) ----------------------------------------------------------------------
 struct Engine {
     void* so = nullptr;
-    bbp_ctx* ctx = nullptr;
+    // one context per GPU (--devices 0,1,..): bids are independent, so connections are dealt round-robin over the contexts and
+    // every context batches its own share (batch-sharded, no cross-GPU traffic at all on this path)
+    std::vector<bbp_ctx*> ctxs;
+    std::atomic<uint64_t> rr{0};
+    bbp_ctx* pick() { return ctxs[rr.fetch_add(1) % ctxs.size()]; }
     decltype(&bbp_init) init = nullptr;
     decltype(&bbp_free) free_ = nullptr;
     decltype(&bbp_prove) prove = nullptr;
@@ -146,6 +151,7 @@ static int read_frame(int fd, tlv::Bytes* payload) {
 
 // ---- one connection: frames until the peer closes (a reference-style client sends one and reads one) -----------------------------
 static void serve(int fd) {
+    bbp_ctx* const ctx = g_eng.pick();  // this connection's GPU
     tlv::Bytes req;
     for (;;) {
         const int got = read_frame(fd, &req);
@@ -164,8 +170,8 @@ static void serve(int fd) {
             uint32_t proof_len = 0;
             if (parse_prove_request(req.data() + 1, req.size() - 1, &pr, &why)) {
                 record.resize(g_eng.record_size(pr.n_items));
-                rc = g_eng.prove(g_eng.ctx, pr.scalars7, pr.pub_list.data(), pr.n_items, pr.toggle, nullptr, record.data(), &proof_len);
-                if (rc != BBP_OK) why = std::string("engine status ") + std::to_string(rc) + ": " + g_eng.last_error(g_eng.ctx);
+                rc = g_eng.prove(ctx, pr.scalars7, pr.pub_list.data(), pr.n_items, pr.toggle, nullptr, record.data(), &proof_len);
+                if (rc != BBP_OK) why = std::string("engine status ") + std::to_string(rc) + ": " + g_eng.last_error(ctx);
             }
             if (rc != BBP_OK) {
                 logf(0, "Error resolving the request: %s", why.c_str());
@@ -179,10 +185,10 @@ static void serve(int fd) {
             VerifyRequest vr;
             uint8_t ok = 0;
             if (parse_verify_request(req.data() + 1, req.size() - 1, &vr, &why)) {
-                const int32_t rc = g_eng.verify(g_eng.ctx, vr.record.data(), (uint32_t)vr.record.size(), vr.score, vr.z_img, vr.seed,
+                const int32_t rc = g_eng.verify(ctx, vr.record.data(), (uint32_t)vr.record.size(), vr.score, vr.z_img, vr.seed,
                                                 vr.pub_list.data(), vr.n_items);
                 ok = rc == BBP_OK;
-                if (rc > BBP_ERR_FORMAT) logf(1, "verify: engine status %d: %s", rc, g_eng.last_error(g_eng.ctx));
+                if (rc > BBP_ERR_FORMAT) logf(1, "verify: engine status %d: %s", rc, g_eng.last_error(ctx));
             } else {
                 logf(3, "verify request rejected while parsing: %s", why.c_str());
             }
@@ -212,7 +218,7 @@ static void on_signal(int) {
 
 static void usage(const char* argv0) {
     fprintf(stderr,
-            "usage: %s [-b|--bind-path PATH] [-l|--log-level error|warn|info|debug|trace] [--engine LIB.so] [--device N]\n"
+            "usage: %s [-b|--bind-path PATH] [-l|--log-level error|warn|info|debug|trace] [--engine LIB.so] [--device N | --devices 0,1,..]\n"
             "          [--window-us US] [--max-batch B] [--max-connections C]\n",
             argv0);
 }
@@ -221,7 +227,7 @@ int main(int argc, char** argv) {
     const char* tmp = getenv("TMPDIR");
     std::string bind_path = std::string(tmp && *tmp ? tmp : "/tmp") + "/dusk-uds-blindbid";  // src/main.rs:14-16
     std::string level = "info", engine_path;
-    int device = 0;
+    std::vector<int> devices;
     uint32_t window_us = 200, max_batch = 4096;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -235,7 +241,15 @@ int main(int argc, char** argv) {
         if (a == "-b" || a == "--bind-path") bind_path = val();
         else if (a == "-l" || a == "--log-level") level = val();
         else if (a == "--engine") engine_path = val();
-        else if (a == "--device") device = atoi(val());
+        else if (a == "--device") devices.assign(1, atoi(val()));
+        else if (a == "--devices") {
+            devices.clear();
+            for (const char* p = val(); *p;) {
+                devices.push_back(atoi(p));
+                while (*p && *p != ',') p++;
+                if (*p == ',') p++;
+            }
+        }
         else if (a == "--window-us") window_us = (uint32_t)atoi(val());
         else if (a == "--max-batch") max_batch = (uint32_t)atoi(val());
         else if (a == "--max-connections") g_max_conn = atoi(val());
@@ -261,13 +275,17 @@ int main(int argc, char** argv) {
         logf(0, "cannot load engine %s: %s", engine_path.c_str(), why.c_str());
         return 1;
     }
-    int32_t rc = g_eng.init(device, &g_eng.ctx);
-    if (rc != BBP_OK) {
-        logf(0, "bbp_init(device %d) failed with status %d: %s (this server has no CPU path)", device, rc,
-             g_eng.ctx ? g_eng.last_error(g_eng.ctx) : "no usable device");
-        return 1;
+    if (devices.empty()) devices.push_back(0);
+    for (int device : devices) {
+        bbp_ctx* c = nullptr;
+        const int32_t rc = g_eng.init(device, &c);
+        if (rc != BBP_OK) {
+            logf(0, "bbp_init(device %d) failed with status %d: %s (this server has no CPU path)", device, rc, c ? g_eng.last_error(c) : "no usable device");
+            return 1;
+        }
+        g_eng.set_batching(c, window_us, max_batch);
+        g_eng.ctxs.push_back(c);
     }
-    g_eng.set_batching(g_eng.ctx, window_us, max_batch);
 
     struct sigaction sa;
     memset(&sa, 0, sizeof sa);
@@ -290,8 +308,8 @@ int main(int argc, char** argv) {
         logf(0, "Failed binding socket %s: %s", bind_path.c_str(), strerror(errno));
         return 1;
     }
-    logf(2, "listening on %s (engine %s, device %d, batching window %u us, max batch %u)", bind_path.c_str(), engine_path.c_str(), device,
-         window_us, max_batch);
+    logf(2, "listening on %s (engine %s, %zu device context(s), batching window %u us, max batch %u)", bind_path.c_str(), engine_path.c_str(),
+         g_eng.ctxs.size(), window_us, max_batch);
     while (!g_stop) {
         int fd = accept(g_listen_fd, nullptr, nullptr);
         if (fd < 0) {
@@ -311,11 +329,19 @@ int main(int argc, char** argv) {
     }
     uint64_t calls = 0, reqs = 0;
     uint32_t biggest = 0;
-    g_eng.batching_stats(g_eng.ctx, &calls, &reqs, &biggest);
+    for (bbp_ctx* c : g_eng.ctxs) {
+        uint64_t a = 0, b = 0;
+        uint32_t m = 0;
+        g_eng.batching_stats(c, &a, &b, &m);
+        calls += a;
+        reqs += b;
+        if (m > biggest) biggest = m;
+    }
     logf(2, "served %llu requests (%llu errors) in %llu device calls, largest batch %u", (unsigned long long)g_served.load(),
          (unsigned long long)g_errors.load(), (unsigned long long)calls, biggest);
     close(g_listen_fd);
     unlink(bind_path.c_str());
-    if (g_live == 0) g_eng.free_(g_eng.ctx);
+    if (g_live == 0)
+        for (bbp_ctx* c : g_eng.ctxs) g_eng.free_(c);
     return 0;
 }

@@ -184,6 +184,33 @@ def test_combiner_keeps_two_batches_in_flight(built):
     assert L.stub_max_concurrency(h) == 2
 
 
+def test_connections_are_dealt_over_several_device_contexts(built):
+    """--devices a,b,..: one engine context per GPU, connections round-robin (independent bids: no cross-GPU traffic on this
+    path).  With the stub both contexts are fakes; the plumbing -- two contexts created, both used, statistics summed -- is real."""
+    built.build_server()
+    stub = built.build_stub_engine()
+    d = tempfile.mkdtemp(prefix="bbp-uds-md-")
+    path, log = os.path.join(d, "sock"), open(os.path.join(d, "log"), "w+")
+    p = subprocess.Popen([built.SERVER_BIN, "-b", path, "--engine", stub, "--devices", "0,1", "--window-us", "0"], stderr=log)
+    try:
+        for _ in range(200):
+            if os.path.exists(path):
+                break
+            time.sleep(0.02)
+        for i in range(6):                                                     # six connections: three per context
+            s7, pub, toggle = _bid(40 + i, 3)
+            blob = uc.prove(path, s7, pub, toggle)
+            assert uc.verify(path, blob, s7[128:160], s7[160:192], s7[192:224], pub) == b"\x01"
+    finally:
+        p.send_signal(signal.SIGTERM)
+        p.wait(timeout=10)
+    log.seek(0)
+    text = log.read()
+    assert "2 device context(s)" in text
+    m = re.search(r"served (\d+) requests \((\d+) errors\) in (\d+) device calls", text)
+    assert m and int(m.group(1)) == 12 and int(m.group(3)) == 12              # window 0, sequential client: one call per request
+
+
 def test_cli_mirrors_the_reference_flags(built):
     built.build_server()
     p = subprocess.run([built.SERVER_BIN, "-l", "loud"], capture_output=True, text=True)
