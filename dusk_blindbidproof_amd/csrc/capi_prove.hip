@@ -13,7 +13,7 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
 int32_t verify_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* ent_dev, int32_t* status_dev, hipStream_t s);
 int32_t verify_batch_dev_ex(bbp_ctx* ctx, u32 B, u32 N, u32 rec_ver, u32 G, const u8* in_dev, const u8* ent_dev, int32_t* status_dev, hipStream_t s);
 int32_t verify_batch_agg_dev(bbp_ctx* ctx, u32 B, u32 N, u32 G, const u8* in_dev, const u8* ent_dev, int32_t* status_dev, hipStream_t s,
-                             u32* n_fallback);
+                             u32* n_fallback, u32* total_out_dev = nullptr);
 int32_t debug_read_misc(bbp_ctx* ctx, u32 B, u32 N, u32 proof, uint8_t* out);
 
 // native (non-circuit) image of the gadget wiring: what the reference's Go caller computes before Proof::prove
@@ -462,6 +462,7 @@ extern "C" int32_t bbp_prove(bbp_ctx* ctx, const uint8_t scalars7[7 * 32], const
 static int32_t verify_batch_host(bbp_ctx* ctx, uint32_t B, uint32_t N, uint32_t rec_ver, const uint8_t* in, int32_t* status,
                                  uint32_t group = 0, uint32_t* n_fallback = nullptr) {
     const size_t stride = (size_t)(rec_ver ? 1217u : 1121u) + 32 * (4 + (size_t)N) + 96 + (size_t)N * 32;
+    if (group == 0 && rec_ver == 0 && ctx->verify_group > 1 && B >= 2 * ctx->verify_group) group = ctx->verify_group;  // BBP_VERIFY_AGGREGATE
     std::vector<uint8_t> ent((size_t)B * 32);
     if (!os_random(ent.data(), ent.size())) {  // Verifier::verify mixes thread_rng into its TranscriptRng (A.7)
         api_guard(ctx, [&]() -> int32_t { return ctx->err = "cannot read /dev/urandom", BBP_ERR_DEVICE; });
@@ -472,7 +473,7 @@ static int32_t verify_batch_host(bbp_ctx* ctx, uint32_t B, uint32_t N, uint32_t 
     int32_t rc = api_guard(ctx, [&]() -> int32_t {
         int32_t rc;
         BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
-        if ((rc = dev_reserve(ctx, sl.out, 4 * (size_t)B)) || (rc = pinned_reserve(ctx, sl.h_out, sl.h_cap, 4 * (size_t)B)) ||
+        if ((rc = dev_reserve(ctx, sl.out, 4 * ((size_t)B + 1))) || (rc = pinned_reserve(ctx, sl.h_out, sl.h_cap, 4 * ((size_t)B + 1))) ||
             (rc = upload_inputs(ctx, sl, in, stride * B, ent.data(), ent.size())))
             return rc;
         const uint32_t n_chunks = (B + host_chunk_verify() - 1) / host_chunk_verify(), chunk = (B + n_chunks - 1) / n_chunks;
@@ -480,10 +481,9 @@ static int32_t verify_batch_host(bbp_ctx* ctx, uint32_t B, uint32_t N, uint32_t 
             const uint32_t nb = B - first < chunk ? B - first : chunk;
             const u8 *cin = (const u8*)sl.in.p + stride * first, *cent = (const u8*)sl.ent.p + 32 * (size_t)first;
             int32_t* cst = (int32_t*)sl.out.p + first;
-            if (group > 1) {
-                uint32_t nf = 0;
-                if ((rc = verify_batch_agg_dev(ctx, nb, N, group, cin, cent, cst, ctx->vstream, &nf))) return rc;
-                if (n_fallback) *n_fallback += nf;
+            if (group > 1) {  // stream-ordered: no synchronisation while the context lock is held
+                if (first == 0 && ctx->agg_count) BBP_HIP_TRY(ctx, hipMemsetAsync(ctx->agg_count + 1, 0, sizeof(u32), ctx->vstream));
+                if ((rc = verify_batch_agg_dev(ctx, nb, N, group, cin, cent, cst, ctx->vstream, nullptr, (u32*)sl.out.p + B))) return rc;
             } else if ((rc = verify_batch_dev_ex(ctx, nb, N, rec_ver, 0, cin, cent, cst, ctx->vstream)))
                 return rc;
         }
@@ -491,8 +491,9 @@ static int32_t verify_batch_host(bbp_ctx* ctx, uint32_t B, uint32_t N, uint32_t 
         return BBP_OK;
     });
     if (rc) return rc;
-    if ((rc = fetch_results(ctx, sl, 4 * (size_t)B))) return rc;
+    if ((rc = fetch_results(ctx, sl, 4 * ((size_t)B + (group > 1 ? 1 : 0))))) return rc;
     memcpy(status, sl.h_out, 4 * (size_t)B);
+    if (group > 1 && n_fallback) memcpy(n_fallback, (const uint8_t*)sl.h_out + 4 * (size_t)B, 4);  // running total of this call's chunks
     return BBP_OK;
 }
 

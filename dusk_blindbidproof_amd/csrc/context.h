@@ -95,6 +95,8 @@ struct bbp_ctx {
     bool ev_done_valid[PROVE_BUFS] = {false, false, false}, ev_open_valid[PROVE_BUFS] = {false, false, false};
     hipEvent_t ev_vfork = nullptr, ev_vjoin = nullptr;  // verifier: variable-base kernel on lane[1] beside the generator MSM
     int verify_overlap = 1;                              // BBP_VERIFY_OVERLAP
+    uint32_t verify_group = 0;  // BBP_VERIFY_AGGREGATE=G: bbp_verify / bbp_verify_batch (host API, hence the UDS server) check proofs in
+                                // groups of G with per-proof fallback -- same statuses, 2-3x the rate; 0 = one MSM per proof like the reference
     uint32_t seq_at_last_verify = 0;                     // prover call counter seen by the last verification (interleaving test)
     hipEvent_t ev_prep = nullptr;  // end of the last bbp_prepare_bids_dev: the next prove call's opening stage waits for it
     bool ev_prep_valid = false;
@@ -124,6 +126,7 @@ struct bbp_ctx {
     bbp::DevBuf slice_sorted[MAX_SLICES + 1], slice_pts[MAX_SLICES + 1], slice_fold[MAX_SLICES], slice_vtab[MAX_SLICES];  // per-slice MSM scratch (slice 0 uses sorted / pts)
     void *agg_vs = nullptr, *agg_varsum = nullptr;  // weighted generator scalars [B][4098] / per-proof variable-base sums of that pass
     int32_t* agg_gstatus = nullptr;  // per-group verdicts of the last aggregated verification (inside agg)
+    bbp::u32* agg_count = nullptr;   // [2] device counters (own allocation): proofs of the current call that take the per-proof path / running total
     // Host-pointer batch calls stage through one of two slots (device in / entropy / out + a pinned host mirror of the results):
     // a call holds the context lock only while it ENQUEUES; it waits for its results on the slot's event with the lock released,
     // so a second host thread can enqueue the next batch meanwhile and the engine's cross-call pipeline (opening stage of call
@@ -274,8 +277,11 @@ int32_t api_guard(bbp_ctx* ctx, F&& body) noexcept {
 
 // msm.hip
 // base_idx_dev holds n_idx_sets lists of n_terms indices; MSM number i uses list (i % n_idx_sets)
+// msm_map_dev / n_active_dev (both or neither): a device-sized launch -- n_msm is the upper bound, *n_active_dev MSMs exist and MSM j
+// takes its scalars from row msm_map_dev[j]
 int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* scalars_dev, const u32* base_idx_dev,
-                   ge* out_points_dev, hipStream_t stream, uint32_t n_idx_sets = 1, int scratch_slot = 0);
+                   ge* out_points_dev, hipStream_t stream, uint32_t n_idx_sets = 1, int scratch_slot = 0, const u32* msm_map_dev = nullptr,
+                   const u32* n_active_dev = nullptr);
 int32_t fold_generators_launch(bbp_ctx* ctx, uint32_t n_proofs, const sc* g_dev, const sc* h_dev, ge* out_dev, hipStream_t stream,
                                int scratch_slot);
 int32_t encode_launch(bbp_ctx* ctx, uint32_t n, const ge* pts_dev, uint8_t* out32_dev, hipStream_t stream);

@@ -150,11 +150,15 @@ template <> struct msm_geom<1> { static constexpr int K = FOLD_K, NAF = FOLD_NAF
 
 template <int MODE>
 __global__ __launch_bounds__(SORT_T) void k_msm_sort(const u32* __restrict__ scal_a, const u32* __restrict__ aux, u32 n_total, u32 n_idx_sets,
-                                                      u32 n_sub, u32 split, u32* __restrict__ sorted_all, u32* __restrict__ cursor_all) {
+                                                      u32 n_sub, u32 split, u32* __restrict__ sorted_all, u32* __restrict__ cursor_all,
+                                                      const u32* __restrict__ msm_map, const u32* __restrict__ n_active) {
     constexpr int K = msm_geom<MODE>::K, NAF = msm_geom<MODE>::NAF, W = msm_geom<MODE>::W, G = K / SORT_T;
     __shared__ u32 cursor[K + 1];  // histogram, then bucket start offsets, then (after the scatter) bucket end offsets
     __shared__ u32 part[SORT_T];
     const int tid = threadIdx.x;
+    // device-sized launches (MODE 0, split = 1): the grid covers the largest possible number of MSMs, *n_active of them exist
+    // (the whole workgroup leaves together), and MSM j takes its scalars from row msm_map[j] of the scalar array
+    if (n_active && blockIdx.x >= *n_active) return;
     // small batches: every MSM is cut into `split` sub-MSMs over n_sub consecutive terms (one workgroup each, summed afterwards)
     const size_t work = blockIdx.x, msm = work / split;
     const u32 i0 = (u32)(work % split) * n_sub;
@@ -164,7 +168,8 @@ __global__ __launch_bounds__(SORT_T) void k_msm_sort(const u32* __restrict__ sca
     const u32* base_idx = nullptr;
     u32 base0 = 0;
     if (MODE == 0) {
-        sbase = scal_a + (msm * (size_t)n_total + i0) * 8;
+        const size_t src = msm_map ? (size_t)msm_map[msm] : msm;
+        sbase = scal_a + (src * (size_t)n_total + i0) * 8;
         base_idx = aux + (size_t)(msm % n_idx_sets) * n_total + i0;
     } else {
         const u32 side = (u32)msm & 1u;  // 0: G with g[], 1: H with h[]
@@ -239,11 +244,12 @@ __global__ __launch_bounds__(SORT_T) void k_msm_sort(const u32* __restrict__ sca
 template <int MODE>
 __global__ __launch_bounds__(MSM_T) __attribute__((amdgpu_waves_per_eu(BBP_MSM_WAVES, BBP_MSM_WAVES_MAX)))
 void k_msm_acc(const niels_row* __restrict__ ptable, const u32* __restrict__ sorted_all, const u32* __restrict__ cursor_all, u32 n /* sorted stride */,
-               ge* __restrict__ bsum_all, ge* __restrict__ psum_all, ge* __restrict__ out) {
+               ge* __restrict__ bsum_all, ge* __restrict__ psum_all, ge* __restrict__ out, const u32* __restrict__ n_active) {
     constexpr int K = msm_geom<MODE>::K, W = msm_geom<MODE>::W, G = K / MSM_T;
     __shared__ u32 cursor[K + 1];
     __shared__ u32 xch[GE_WORDS];
     const int tid = threadIdx.x;
+    if (n_active && blockIdx.x >= *n_active) return;  // device-sized launch (see k_msm_sort)
     const size_t msm = blockIdx.x;
     const u32* sorted = sorted_all + msm * (size_t)n * W;
 #ifdef BBP_MSM_PRIO
@@ -461,7 +467,9 @@ static MsmScratch msm_scratch_layout(void* base, size_t n_msm, size_t n_terms, s
 }
 size_t msm_scratch_bytes(uint32_t n_msm, uint32_t n_terms) {
     const u32 split = msm_split(n_msm, n_terms), n_sub = (n_terms + split - 1) / split;
-    return msm_scratch_layout(nullptr, (size_t)n_msm * split, n_sub, MSM_W, MSM_K).bytes;
+    const size_t a = msm_scratch_layout(nullptr, (size_t)n_msm * split, n_sub, MSM_W, MSM_K).bytes;
+    const size_t b = msm_scratch_layout(nullptr, n_msm, n_terms, MSM_W, MSM_K).bytes;  // the unsplit layout of a device-sized launch
+    return a > b ? a : b;
 }
 
 int32_t fold_generators_launch(bbp_ctx* ctx, uint32_t n_proofs, const sc* g_dev, const sc* h_dev, ge* out_dev, hipStream_t stream,
@@ -477,12 +485,12 @@ int32_t fold_generators_launch(bbp_ctx* ctx, uint32_t n_proofs, const sc* g_dev,
     {
         ScopedEvent ev(ctx, TAG_MSM_SORT, stream);
         hipLaunchKernelGGL(k_msm_sort<1>, dim3((u32)n_work), dim3(SORT_T), 0, stream, (const u32*)g_dev, (const u32*)h_dev, 2048u, 1u, n_sub, split,
-                           m.sorted, m.cursor);
+                           m.sorted, m.cursor, (const u32*)nullptr, (const u32*)nullptr);
         BBP_HIP_TRY(ctx, hipGetLastError());
     }
     ScopedEvent ev(ctx, TAG_MSM, stream);
     hipLaunchKernelGGL(k_msm_acc<1>, dim3((u32)n_work), dim3(MSM_T), 0, stream, ctx->ptable, m.sorted, m.cursor, n_sub, m.bsum, m.psum,
-                       split > 1 ? m.tmp : out_dev);
+                       split > 1 ? m.tmp : out_dev, (const u32*)nullptr);
     BBP_HIP_TRY(ctx, hipGetLastError());
     if (split > 1) {
         const u32 n_out = (u32)n_msm * FOLD_CLS;
@@ -504,7 +512,8 @@ __global__ __launch_bounds__(64) void k_encode(const ge* __restrict__ pts, u32 n
 }
 
 int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* scalars_dev, const u32* base_idx_dev,
-                   ge* out_points_dev, hipStream_t stream, uint32_t n_idx_sets, int scratch_slot) {
+                   ge* out_points_dev, hipStream_t stream, uint32_t n_idx_sets, int scratch_slot, const u32* msm_map_dev,
+                   const u32* n_active_dev) {
     if (n_msm == 0) return BBP_OK;
     if (n_terms == 0 || n_terms > 65535u) {
         ctx->err = "msm_launch: n_terms out of range";
@@ -513,18 +522,19 @@ int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* sc
     DevBuf& scratch = scratch_slot ? ctx->slice_sorted[scratch_slot] : ctx->sorted;  // one scratch area per concurrently running stream
     int32_t rc = dev_reserve(ctx, scratch, msm_scratch_bytes(n_msm, n_terms));
     if (rc) return rc;
-    const u32 split = msm_split(n_msm, n_terms), n_sub = (n_terms + split - 1) / split;
+    // device-sized launches (n_active_dev: n_msm is only the upper bound of how many MSMs there are) are never split
+    const u32 split = n_active_dev ? 1u : msm_split(n_msm, n_terms), n_sub = (n_terms + split - 1) / split;
     const u32 n_work = n_msm * split;
     const MsmScratch m = msm_scratch_layout(scratch.p, n_work, n_sub, MSM_W, MSM_K);
     {
         ScopedEvent ev(ctx, TAG_MSM_SORT, stream);
         hipLaunchKernelGGL(k_msm_sort<0>, dim3(n_work), dim3(SORT_T), 0, stream, scalars_dev, base_idx_dev, n_terms, n_idx_sets, n_sub, split,
-                           m.sorted, m.cursor);
+                           m.sorted, m.cursor, msm_map_dev, n_active_dev);
         BBP_HIP_TRY(ctx, hipGetLastError());
     }
     ScopedEvent ev(ctx, TAG_MSM, stream);
     hipLaunchKernelGGL(k_msm_acc<0>, dim3(n_work), dim3(MSM_T), 0, stream, ctx->ptable, m.sorted, m.cursor, n_sub, m.bsum, m.psum,
-                       split > 1 ? m.tmp : out_points_dev);
+                       split > 1 ? m.tmp : out_points_dev, n_active_dev);
     BBP_HIP_TRY(ctx, hipGetLastError());
     if (split > 1) {
         hipLaunchKernelGGL(k_msm_reduce, dim3((n_msm + 63) / 64), dim3(64), lds_token(ctx), stream, n_msm, split, 1u, m.tmp, out_points_dev);

@@ -164,6 +164,7 @@ static int32_t init_body(int32_t device, bbp_ctx** out) {
     BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_vfork, hipEventDisableTiming));
     BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_vjoin, hipEventDisableTiming));
     if (const char* e = getenv("BBP_VERIFY_OVERLAP")) ctx->verify_overlap = atoi(e) != 0;
+    if (const char* e = getenv("BBP_VERIFY_AGGREGATE")) ctx->verify_group = atoi(e) > 1 ? (uint32_t)atoi(e) : 0u;
     if (const char* e = getenv("BBP_DUAL_OPEN_BELOW")) ctx->dual_open_below = atoi(e);
     if (const char* e = getenv("BBP_VARBASE_LANES")) ctx->varbase_lanes = atoi(e) < 64 ? 64 : atoi(e);
     if (const char* e = getenv("BBP_TAIL_ROUND")) ctx->tail_round = atoi(e) == bbp::FOLD_ROUND ? bbp::FOLD_ROUND : 12;
@@ -247,6 +248,7 @@ extern "C" void bbp_free(bbp_ctx* ctx) {
         if (sl.ev) (void)hipEventDestroy(sl.ev);
         if (sl.ev_in) (void)hipEventDestroy(sl.ev_in);
     }
+    if (ctx->agg_count) (void)hipFree(ctx->agg_count);
     for (auto& kv : ctx->layout_idx)
         if (kv.second) (void)hipFree(kv.second);
     ctx->layout_idx.clear();

@@ -148,7 +148,9 @@ int32_t bbp_verify_batch_dev(bbp_ctx* ctx, uint32_t B, uint32_t N, const void* i
  * per-proof mega-checks are summed with random weights drawn from each proof's verifier TranscriptRng (seeded by the OS /
  * entropy_dev).  The members of every group that fails are then checked one by one (an MSM each over the scalars already
  * computed), so status[] is what bbp_verify_batch reports (a bad proof slipping through needs a ~2^-250 accident).  Same record layout as bbp_verify_batch.  *n_fallback (may be NULL)
- * receives how many proofs were checked individually.  The _dev variant synchronises `stream` before it returns. */
+ * receives how many proofs were checked individually.  The _dev variant is stream-ordered like bbp_verify_batch_dev -- which
+ * groups failed is decided on the device, the per-proof pass sizes itself from a device counter -- unless n_fallback is non-NULL:
+ * delivering that count synchronises `stream`. */
 #define BBP_AGG_GROUP_DEFAULT 32u
 int32_t bbp_verify_batch_aggregated(bbp_ctx* ctx, uint32_t B, uint32_t N, const uint8_t* in, int32_t* status, uint32_t group,
                                     uint32_t* n_fallback);
