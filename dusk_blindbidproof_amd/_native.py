@@ -202,10 +202,13 @@ class Context:
         self._check(lib.bbp_verify_batch_aggregated(self._h, B, N, _buf(inputs), status, group, ctypes.byref(nfb)))
         return list(status), nfb.value
 
-    def verify_batch_aggregated_dev(self, B, N, in_ptr, ent_ptr, status_ptr, group=0, stream=None):
+    def verify_batch_aggregated_dev(self, B, N, in_ptr, ent_ptr, status_ptr, group=0, stream=None, want_count=True):
+        """Stream-ordered unless the fallback count is asked for (delivering it synchronises the stream): want_count=False
+        returns None and leaves the call asynchronous like verify_batch_dev."""
         nfb = ctypes.c_uint32()
-        self._check(lib.bbp_verify_batch_aggregated_dev(self._h, B, N, in_ptr, ent_ptr, status_ptr, group, ctypes.byref(nfb), _stream(stream)))
-        return nfb.value
+        self._check(lib.bbp_verify_batch_aggregated_dev(self._h, B, N, in_ptr, ent_ptr, status_ptr, group,
+                                                        ctypes.byref(nfb) if want_count else None, _stream(stream)))
+        return nfb.value if want_count else None
 
     def prove_batch_dev(self, B, N, in_ptr, ent_ptr, out_ptr, stream=None):
         self._check(lib.bbp_prove_batch_dev(self._h, B, N, in_ptr, ent_ptr, out_ptr, _stream(stream)))

@@ -153,6 +153,41 @@ def test_config4_streaming_prove_verify_no_host_sync(ctx, oc, bbp):
     assert oc.verify(first, w[128:160], w[160:192], seed_sc, bytes(pub0)) == 0
 
 
+def test_aggregated_verification_is_stream_ordered(ctx, bbp):
+    """bbp_verify_batch_aggregated_dev with n_fallback = NULL makes no host round trip: which groups failed is decided on the
+    device and the per-proof pass sizes itself from a device counter.  Six calls back to back on one stream over different
+    corruption patterns (none, a few, a whole group, most of the batch), status buffers read only after ONE synchronisation at
+    the end; every call must report exactly what the per-proof path reports."""
+    import torch
+    dev = torch.device("cuda", 0)
+    N, distinct, B = 8, 48, 700
+    ins, ents, vins = _synth_batch(ctx, distinct, N, seed=161803)
+    out, st = ctx.prove_batch(distinct, N, b"".join(ins), b"".join(ents))
+    assert st == [0] * distinct
+    rs_ = bbp.record_size(N)
+    base = [out[(i % distinct) * rs_:(i % distinct + 1) * rs_] + b"".join(vins[i % distinct]) for i in range(B)]
+    patterns = [set(), {5, 6, 7, 300}, set(range(64, 96)), {B - 1}, set(range(0, B, 2)), set()]
+    blobs, d_in, d_st = [], [], []
+    for bad in patterns:
+        rows = [bytearray(r) for r in base]
+        for i in bad:
+            rows[i][1 + (i * 13) % 1000] ^= 1 << (i % 7)
+        blobs.append(b"".join(bytes(r) for r in rows))
+        d_in.append(torch.frombuffer(bytearray(blobs[-1]), dtype=torch.uint8).to(dev))
+        d_st.append(torch.full((B,), -1, dtype=torch.int32, device=dev))
+    d_ent = torch.zeros(32 * B, dtype=torch.uint8, device=dev)
+    s = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        for k in range(len(patterns)):
+            assert ctx.verify_batch_aggregated_dev(B, N, d_in[k].data_ptr(), d_ent.data_ptr(), d_st[k].data_ptr(), 32, s.cuda_stream, want_count=False) is None
+    s.synchronize()
+    for k, bad in enumerate(patterns):
+        got = d_st[k].cpu().tolist()
+        assert got == ctx.verify_batch(B, N, blobs[k]), k
+        assert {i for i, v in enumerate(got) if v != 0} == bad, k
+
+
 # ---- a9: Scalar::from_bits semantics on the device path ------------------------------------------------------------------------
 NONCANON = [L, L + 1, 2**255 - 1, 2**255 + 12345, 2**256 - 1, 2**255 + L + 7]
 
