@@ -279,7 +279,13 @@ class VerifyWorkload(_Base):
         self.rows = rows
         self.in_dev = _to_dev(torch, device, b"".join(bytes(r) for r in rows))
         self.ent_dev = _to_dev(torch, device, hashlib.shake_256(b"verifier-entropy%d" % seed).digest(32 * batch))
-        self.status = torch.full((batch,), -1, dtype=torch.int32, device=device)
+        # consecutive steps alternate between the verifier's two lanes (include/bbp.h bbp_context_verify_stream): the front end
+        # of one call runs under the generator MSM of the other; BBP_BENCH_VERIFY_LANES=1 keeps every step on one stream
+        self.lanes = 1 if os.environ.get("BBP_BENCH_VERIFY_LANES") == "1" else 2
+        self.lane_streams = [torch.cuda.ExternalStream(ctx.verify_stream(i), device=device) for i in range(self.lanes)]
+        self.lane_status = [torch.full((batch,), -1, dtype=torch.int32, device=device) for _ in range(self.lanes)]
+        self.status = self.lane_status[0]
+        self.k = 0
         self.units_per_step = batch
         self.alg_bytes_per_step = batch * ((4135 + items) * 160 + 32)   # verify = 4135 + N terms
         self.row_additions_per_step = batch * 4098 * NAF12_DIGITS      # the fixed-base mega-check MSM launch
@@ -289,10 +295,18 @@ class VerifyWorkload(_Base):
                        % ("configs[3] shard: " if batch == 8192 else "", batch, items, len(self.bad), distinct),
                        "batch_per_gpu": batch, "bid_list_len": items, "parallelism": "batch-sharded, flags gathered to rank 0"}
 
+    def _lane(self):
+        i = self.k % self.lanes
+        self.k += 1
+        self.status = self.lane_status[i]
+        return self.lane_streams[i].cuda_stream, self.status
+
     def step(self, stream):
-        self.ctx.verify_batch_dev(self.B, self.N, self.in_dev.data_ptr(), self.ent_dev.data_ptr(), self.status.data_ptr(), stream)
+        s, st = self._lane()
+        self.ctx.verify_batch_dev(self.B, self.N, self.in_dev.data_ptr(), self.ent_dev.data_ptr(), st.data_ptr(), s)
 
     def check(self):
+        self.torch.cuda.synchronize()
         st = self.status.cpu().tolist()
         exp = [0] * self.B
         for i in self.bad:
@@ -327,7 +341,7 @@ class VerifyWorkload(_Base):
 class VerifyAggregatedWorkload(VerifyWorkload):
     """The same B verifications (1 % corrupted) through bbp_verify_batch_aggregated_dev: groups of 32 proofs share one weighted
     generator MSM, the members of failing groups are re-verified one by one; statuses as the per-proof path reports them.
-    The call synchronises the stream itself (the host reads the group verdicts)."""
+    Stream-ordered since round 2 (failing groups are compacted on the device)."""
 
     metric = "blind-bid verifies/sec (aggregated, SURVEY 8f-4 extension)"
 
@@ -338,8 +352,11 @@ class VerifyAggregatedWorkload(VerifyWorkload):
         self.config = dict(self.config, workload=self.config["workload"] + ", aggregated in groups of %d with per-proof fallback" % self.group)
 
     def step(self, stream):
-        self.n_fallback = self.ctx.verify_batch_aggregated_dev(self.B, self.N, self.in_dev.data_ptr(), self.ent_dev.data_ptr(),
-                                                               self.status.data_ptr(), self.group, stream)
+        s, st = self._lane()
+        nf = self.ctx.verify_batch_aggregated_dev(self.B, self.N, self.in_dev.data_ptr(), self.ent_dev.data_ptr(), st.data_ptr(), self.group, s,
+                                                  want_count=self.k <= self.lanes)  # the count once per lane (it synchronises), then stream-ordered
+        if nf is not None:
+            self.n_fallback = nf
         # MSMs the engine actually ran: one per group plus one per re-verified proof
         n_msm = (self.B + self.group - 1) // self.group + self.n_fallback
         self.row_additions_per_step = n_msm * 4098 * NAF12_DIGITS

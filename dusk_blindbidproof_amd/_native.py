@@ -25,6 +25,7 @@ SIGNATURES = {
     "bbp_last_error": (_cp, [_vp]),
     "bbp_context_stream": (_vp, [_vp]),
     "bbp_context_copy_stream": (_vp, [_vp]),
+    "bbp_context_verify_stream": (_vp, [_vp, _u32]),
     "bbp_get_generator": (_i32, [_vp, _u32, _vp]),
     "bbp_get_mimc_constant": (_i32, [_vp, _u32, _vp]),
     "bbp_msm_batch": (_i32, [_vp, _u32, _u32, _vp, _u32, _vp]),
@@ -215,6 +216,10 @@ class Context:
 
     def verify_batch_dev(self, B, N, in_ptr, ent_ptr, status_ptr, stream=None):
         self._check(lib.bbp_verify_batch_dev(self._h, B, N, in_ptr, ent_ptr, status_ptr, _stream(stream)))
+
+    def verify_stream(self, lane):
+        """hipStream_t handle of verifier lane 0 / 1: verification calls on the two lanes' streams overlap on the device."""
+        return lib.bbp_context_verify_stream(self._h, lane)
 
     def set_batching(self, window_us=0, max_batch=0):
         """Micro-batching window / size bound of the call combiner (concurrent prove() / verify() callers share device batches)."""

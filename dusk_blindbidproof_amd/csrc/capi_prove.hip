@@ -470,6 +470,7 @@ static int32_t verify_batch_host(bbp_ctx* ctx, uint32_t B, uint32_t N, uint32_t 
     }
     SlotLease lease(ctx);
     bbp_ctx::IoSlot& sl = *lease.sl;
+    bbp_ctx::VLane& L = ctx->vl[(&sl - ctx->io) % bbp_ctx::VLANES];  // verifier lane = staging slot: consecutive host calls overlap on the device
     int32_t rc = api_guard(ctx, [&]() -> int32_t {
         int32_t rc;
         BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -482,12 +483,12 @@ static int32_t verify_batch_host(bbp_ctx* ctx, uint32_t B, uint32_t N, uint32_t 
             const u8 *cin = (const u8*)sl.in.p + stride * first, *cent = (const u8*)sl.ent.p + 32 * (size_t)first;
             int32_t* cst = (int32_t*)sl.out.p + first;
             if (group > 1) {  // stream-ordered: no synchronisation while the context lock is held
-                if (first == 0 && ctx->agg_count) BBP_HIP_TRY(ctx, hipMemsetAsync(ctx->agg_count + 1, 0, sizeof(u32), ctx->vstream));
-                if ((rc = verify_batch_agg_dev(ctx, nb, N, group, cin, cent, cst, ctx->vstream, nullptr, (u32*)sl.out.p + B))) return rc;
-            } else if ((rc = verify_batch_dev_ex(ctx, nb, N, rec_ver, 0, cin, cent, cst, ctx->vstream)))
+                if (first == 0 && L.agg_count) BBP_HIP_TRY(ctx, hipMemsetAsync(L.agg_count + 1, 0, sizeof(u32), L.stream));
+                if ((rc = verify_batch_agg_dev(ctx, nb, N, group, cin, cent, cst, L.stream, nullptr, (u32*)sl.out.p + B))) return rc;
+            } else if ((rc = verify_batch_dev_ex(ctx, nb, N, rec_ver, 0, cin, cent, cst, L.stream)))
                 return rc;
         }
-        BBP_HIP_TRY(ctx, hipEventRecord(sl.ev, ctx->vstream));
+        BBP_HIP_TRY(ctx, hipEventRecord(sl.ev, L.stream));
         return BBP_OK;
     });
     if (rc) return rc;

@@ -93,7 +93,6 @@ struct bbp_ctx {
     hipEvent_t ev_open[PROVE_BUFS] = {nullptr, nullptr, nullptr}, ev_done[PROVE_BUFS] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_entry[PROVE_BUFS] = {nullptr, nullptr, nullptr};  // caller's stream at entry of a prove call: out_dev is not written before it
     bool ev_done_valid[PROVE_BUFS] = {false, false, false}, ev_open_valid[PROVE_BUFS] = {false, false, false};
-    hipEvent_t ev_vfork = nullptr, ev_vjoin = nullptr;  // verifier: variable-base kernel on lane[1] beside the generator MSM
     int verify_overlap = 1;                              // BBP_VERIFY_OVERLAP
     uint32_t verify_group = 0;  // BBP_VERIFY_AGGREGATE=G: bbp_verify / bbp_verify_batch (host API, hence the UDS server) check proofs in
                                 // groups of G with per-proof fallback -- same statuses, 2-3x the rate; 0 = one MSM per proof like the reference
@@ -107,10 +106,24 @@ struct bbp_ctx {
     // two families with disjoint scratch: 0 = prover, MSM hook, witness, setup read-backs; 1 = verifier (its own batch buffer,
     // misc scratch and MSM scratch slot VERIFY_SLOT) -- a verification issued on another stream than a prove call is NOT ordered
     // behind it and overlaps its heavy stage on the device
-    hipStream_t last_stream[2] = {nullptr, nullptr};
-    hipEvent_t ev_last[2] = {nullptr, nullptr};
-    bool ev_last_valid[2] = {false, false};
-    hipStream_t vstream = nullptr;  // the host-pointer verify calls run here (prove calls on `stream`)
+    static constexpr int FAMILIES = 3;  // prover | verifier lane 0 | verifier lane 1
+    hipStream_t last_stream[FAMILIES] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_last[FAMILIES] = {nullptr, nullptr, nullptr};
+    bool ev_last_valid[FAMILIES] = {false, false, false};
+    // Two verifier LANES, each with everything a verification call touches (batch buffer, scratch, MSM scratch slot, aggregation
+    // buffers, a stream): two calls on the two lanes share nothing, so the front end of one (parse, transcripts, powers, flatten,
+    // scalars: latency-bound) runs under the MSM of the other.  The host-pointer API alternates lanes with its staging slots;
+    // device-API callers pick a lane by passing that lane's stream (bbp_context_verify_stream), any other stream is lane 0.
+    static constexpr int VLANES = 2;
+    struct VLane {
+        hipStream_t stream = nullptr;
+        bbp::DevBuf misc, agg, agg_io;
+        void *agg_vs = nullptr, *agg_varsum = nullptr;  // weighted generator scalars [B][4098] / per-proof variable-base sums of the last group pass
+        int32_t* agg_gstatus = nullptr;                 // per-group verdicts of that pass (inside agg)
+        bbp::u32* agg_count = nullptr;                  // [2] device counters: proofs of the current call on the per-proof path / running total
+        hipEvent_t ev_vfork = nullptr, ev_vjoin = nullptr;  // variable-base kernel on lane[1] beside the generator MSM (lane 0 only)
+    };
+    VLane vl[VLANES];
     std::string err;
     // resident tables
     bbp::ge* gens = nullptr;           // [TAB_BASES] extended points: B_blinding, G[2048], H[2048], B, then the PAD_BASES range sums and the MRG_BASES merged bases
@@ -121,12 +134,9 @@ struct bbp_ctx {
     uint8_t gens_enc_host_valid = 0;
     std::vector<uint8_t> mimc_host;    // 90 * 32
     // grow-only scratch
-    bbp::DevBuf scal, idx, sorted, pts, enc, misc, batch[PROVE_BUFS + 1], io_in, io_out, io_ent, raw[2], agg, agg_io;  // batch[3]: the verifier's; raw[i]: draw buffer of opening stream i
-    static constexpr int VERIFY_SLOT = MAX_SLICES;  // MSM scratch slot of the verifier
-    bbp::DevBuf slice_sorted[MAX_SLICES + 1], slice_pts[MAX_SLICES + 1], slice_fold[MAX_SLICES], slice_vtab[MAX_SLICES];  // per-slice MSM scratch (slice 0 uses sorted / pts)
-    void *agg_vs = nullptr, *agg_varsum = nullptr;  // weighted generator scalars [B][4098] / per-proof variable-base sums of that pass
-    int32_t* agg_gstatus = nullptr;  // per-group verdicts of the last aggregated verification (inside agg)
-    bbp::u32* agg_count = nullptr;   // [2] device counters (own allocation): proofs of the current call that take the per-proof path / running total
+    bbp::DevBuf scal, idx, sorted, pts, enc, batch[PROVE_BUFS + VLANES], io_in, io_out, io_ent, raw[2];  // batch[3 + lane]: the verifier lanes'; raw[i]: draw buffer of opening stream i
+    static constexpr int VERIFY_SLOT = MAX_SLICES;  // MSM scratch slots of the verifier lanes: VERIFY_SLOT + lane
+    bbp::DevBuf slice_sorted[MAX_SLICES + VLANES], slice_pts[MAX_SLICES + VLANES], slice_fold[MAX_SLICES], slice_vtab[MAX_SLICES];  // per-slice MSM scratch (slice 0 uses sorted / pts)
     // Host-pointer batch calls stage through one of two slots (device in / entropy / out + a pinned host mirror of the results):
     // a call holds the context lock only while it ENQUEUES; it waits for its results on the slot's event with the lock released,
     // so a second host thread can enqueue the next batch meanwhile and the engine's cross-call pipeline (opening stage of call
@@ -217,7 +227,7 @@ inline int32_t serial_lds_bytes(bbp_ctx* ctx, const void* kernel) {
 struct StreamGuard {
     bbp_ctx* ctx;
     hipStream_t s;
-    int fam;  // 0: prover family, 1: verifier family (context.h: disjoint scratch, no ordering between the two)
+    int fam;  // 0: prover family, 1 + lane: a verifier lane (context.h: disjoint scratch, no ordering between families)
     bool entered = false;
     StreamGuard(bbp_ctx* c, hipStream_t st, int family = 0) : ctx(c), s(st), fam(family) {}
     int32_t enter() {

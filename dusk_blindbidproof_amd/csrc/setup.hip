@@ -153,16 +153,17 @@ static int32_t init_body(int32_t device, bbp_ctx** out) {
     // stage keeps busy (stream, side, lane[1], lane[2]) must not share one (measured: with the copy stream created third, a
     // 1024-proof batch took 60.9 instead of 55.6 ms)
     BBP_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking));
-    BBP_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->vstream, hipStreamNonBlocking));
-    BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_last[0], hipEventDisableTiming));
-    BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_last[1], hipEventDisableTiming));
+    for (auto& L : ctx->vl) {
+        BBP_HIP_TRY(ctx, hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+        BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&L.ev_vfork, hipEventDisableTiming));
+        BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&L.ev_vjoin, hipEventDisableTiming));
+    }
+    for (int f = 0; f < bbp_ctx::FAMILIES; f++) BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_last[f], hipEventDisableTiming));
     for (auto& sl : ctx->io) {
         BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
         BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming));
     }
     BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming));
-    BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_vfork, hipEventDisableTiming));
-    BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_vjoin, hipEventDisableTiming));
     if (const char* e = getenv("BBP_VERIFY_OVERLAP")) ctx->verify_overlap = atoi(e) != 0;
     if (const char* e = getenv("BBP_VERIFY_AGGREGATE")) ctx->verify_group = atoi(e) > 1 ? (uint32_t)atoi(e) : 0u;
     if (const char* e = getenv("BBP_DUAL_OPEN_BELOW")) ctx->dual_open_below = atoi(e);
@@ -228,7 +229,7 @@ extern "C" void bbp_free(bbp_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     void* ptrs[] = {ctx->gens, ctx->ptable, ctx->btab, ctx->slice_fold[0].p, ctx->slice_fold[1].p, ctx->slice_fold[2].p, ctx->slice_fold[3].p,
-                    ctx->slice_vtab[0].p, ctx->slice_vtab[1].p, ctx->slice_vtab[2].p, ctx->slice_vtab[3].p, ctx->comb, ctx->mimc_c, ctx->scal.p, ctx->idx.p, ctx->sorted.p, ctx->pts.p, ctx->enc.p, ctx->misc.p, ctx->batch[0].p, ctx->io_in.p, ctx->io_out.p, ctx->io_ent.p, ctx->raw[0].p, ctx->raw[1].p, ctx->agg.p, ctx->agg_io.p, ctx->batch[1].p, ctx->batch[2].p, ctx->batch[3].p, ctx->slice_sorted[1].p, ctx->slice_sorted[2].p, ctx->slice_sorted[3].p, ctx->slice_pts[1].p, ctx->slice_pts[2].p, ctx->slice_pts[3].p, ctx->slice_sorted[4].p, ctx->slice_pts[4].p};
+                    ctx->slice_vtab[0].p, ctx->slice_vtab[1].p, ctx->slice_vtab[2].p, ctx->slice_vtab[3].p, ctx->comb, ctx->mimc_c, ctx->scal.p, ctx->idx.p, ctx->sorted.p, ctx->pts.p, ctx->enc.p, ctx->batch[0].p, ctx->io_in.p, ctx->io_out.p, ctx->io_ent.p, ctx->raw[0].p, ctx->raw[1].p, ctx->batch[1].p, ctx->batch[2].p, ctx->batch[3].p, ctx->batch[4].p, ctx->slice_sorted[5].p, ctx->slice_pts[5].p, ctx->slice_sorted[1].p, ctx->slice_sorted[2].p, ctx->slice_sorted[3].p, ctx->slice_pts[1].p, ctx->slice_pts[2].p, ctx->slice_pts[3].p, ctx->slice_sorted[4].p, ctx->slice_pts[4].p};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& kv : ctx->circuits) {  // compiled circuits (one per list length used)
@@ -248,7 +249,13 @@ extern "C" void bbp_free(bbp_ctx* ctx) {
         if (sl.ev) (void)hipEventDestroy(sl.ev);
         if (sl.ev_in) (void)hipEventDestroy(sl.ev_in);
     }
-    if (ctx->agg_count) (void)hipFree(ctx->agg_count);
+    for (auto& L : ctx->vl) {
+        for (void* p : {L.misc.p, L.agg.p, L.agg_io.p, (void*)L.agg_count})
+            if (p) (void)hipFree(p);
+        if (L.ev_vfork) (void)hipEventDestroy(L.ev_vfork);
+        if (L.ev_vjoin) (void)hipEventDestroy(L.ev_vjoin);
+        if (L.stream) (void)hipStreamDestroy(L.stream);
+    }
     for (auto& kv : ctx->layout_idx)
         if (kv.second) (void)hipFree(kv.second);
     ctx->layout_idx.clear();
@@ -264,12 +271,9 @@ extern "C" void bbp_free(bbp_ctx* ctx) {
         if (ctx->ev_stagger[i - 1]) (void)hipEventDestroy(ctx->ev_stagger[i - 1]);
         if (ctx->lane[i]) (void)hipStreamDestroy(ctx->lane[i]);
     }
-    for (int f = 0; f < 2; f++)
+    for (int f = 0; f < bbp_ctx::FAMILIES; f++)
         if (ctx->ev_last[f]) (void)hipEventDestroy(ctx->ev_last[f]);
-    if (ctx->vstream) (void)hipStreamDestroy(ctx->vstream);
     if (ctx->ev_prep) (void)hipEventDestroy(ctx->ev_prep);
-    if (ctx->ev_vfork) (void)hipEventDestroy(ctx->ev_vfork);
-    if (ctx->ev_vjoin) (void)hipEventDestroy(ctx->ev_vjoin);
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
     if (ctx->copy) (void)hipStreamDestroy(ctx->copy);
     if (ctx->side2) (void)hipStreamDestroy(ctx->side2);
@@ -295,6 +299,7 @@ extern "C" const char* bbp_last_error(const bbp_ctx* ctx) {
 
 extern "C" void* bbp_context_stream(bbp_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 extern "C" void* bbp_context_copy_stream(bbp_ctx* ctx) { return ctx ? (void*)ctx->copy : nullptr; }
+extern "C" void* bbp_context_verify_stream(bbp_ctx* ctx, uint32_t lane) { return ctx && lane < bbp_ctx::VLANES ? (void*)ctx->vl[lane].stream : nullptr; }
 
 extern "C" int32_t bbp_get_generator(bbp_ctx* ctx, uint32_t index, uint8_t out32[32]) {
     if (!ctx || index >= BBP_NUM_BASES) return BBP_ERR_BAD_ARG;

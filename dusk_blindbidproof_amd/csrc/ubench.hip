@@ -98,8 +98,8 @@ extern "C" int32_t bbp_ubench(bbp_ctx* ctx, int32_t kind, uint32_t blocks, uint3
     if (!ctx || !ops_per_sec || kind < 0 || kind > 5 || blocks == 0) return BBP_ERR_BAD_ARG;
     return api_guard(ctx, [&]() -> int32_t {
     BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    BBP_HIP_TRY(ctx, hipDeviceSynchronize());  // ctx->misc is the verifier's scratch: nothing of this context may still be using it
-    int32_t rc = dev_reserve(ctx, ctx->misc, (size_t)blocks * 256 * 4);
+    BBP_HIP_TRY(ctx, hipDeviceSynchronize());  // ctx->vl[0].misc is the verifier's scratch: nothing of this context may still be using it
+    int32_t rc = dev_reserve(ctx, ctx->vl[0].misc, (size_t)blocks * 256 * 4);
     if (rc) return rc;
     hipEvent_t a, b;
     BBP_HIP_TRY(ctx, hipEventCreate(&a));
@@ -107,9 +107,9 @@ extern "C" int32_t bbp_ubench(bbp_ctx* ctx, int32_t kind, uint32_t blocks, uint3
     const char* lds_env = getenv("BBP_UBENCH_LDS");
     const unsigned lds = lds_env ? (unsigned)atoi(lds_env) : 0u;
     if (lds > 64 * 1024) BBP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ubench, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_ubench, dim3(blocks), dim3(256), lds, ctx->stream, kind, iters / 8 + 1, (u32*)ctx->misc.p);  // warm-up
+    hipLaunchKernelGGL(k_ubench, dim3(blocks), dim3(256), lds, ctx->stream, kind, iters / 8 + 1, (u32*)ctx->vl[0].misc.p);  // warm-up
     BBP_HIP_TRY(ctx, hipEventRecord(a, ctx->stream));
-    hipLaunchKernelGGL(k_ubench, dim3(blocks), dim3(256), lds, ctx->stream, kind, iters, (u32*)ctx->misc.p);
+    hipLaunchKernelGGL(k_ubench, dim3(blocks), dim3(256), lds, ctx->stream, kind, iters, (u32*)ctx->vl[0].misc.p);
     BBP_HIP_TRY(ctx, hipEventRecord(b, ctx->stream));
     BBP_HIP_TRY(ctx, hipEventSynchronize(b));
     float ms = 0;
