@@ -45,6 +45,7 @@ SIGNATURES = {
     "bbp_set_batching": (_i32, [_vp, _u32, _u32]),
     "bbp_batching_stats": (_i32, [_vp, ctypes.POINTER(_u64), ctypes.POINTER(_u64), ctypes.POINTER(_u32)]),
     "bbp_debug_compile_circuit": (_i32, [_u32, ctypes.POINTER(_u32), ctypes.POINTER(_u32)]),
+    "bbp_check_health": (_i32, [_vp, ctypes.POINTER(_u32)]),
     "bbp_debug_challenges": (_i32, [_vp, _u32, _u32, _u32, _vp]),
     "bbp_ubench": (_i32, [_vp, _i32, _u32, _u32, ctypes.POINTER(ctypes.c_double)]),
     "bbp_set_profiling": (_i32, [_vp, _i32]),
@@ -230,6 +231,12 @@ class Context:
         a, b, c = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint32()
         self._check(lib.bbp_batching_stats(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
         return a.value, b.value, c.value
+
+    def health(self):
+        """0 = healthy; bit 0 = an MSM gather had to be clamped since the context was created (include/bbp.h bbp_check_health)."""
+        f = ctypes.c_uint32()
+        self._check(lib.bbp_check_health(self._h, ctypes.byref(f)))
+        return f.value
 
     def debug_challenges(self, B, N, proof):
         out = (ctypes.c_uint8 * (32 * 32))()

@@ -125,6 +125,7 @@ struct bbp_ctx {
     };
     VLane vl[VLANES];
     std::string err;
+    bbp::u32* health = nullptr;  // device word, bit 0: an MSM table gather had to be clamped (corrupted scratch) -- bbp_check_health
     // resident tables
     bbp::ge* gens = nullptr;           // [TAB_BASES] extended points: B_blinding, G[2048], H[2048], B, then the PAD_BASES range sums and the MRG_BASES merged bases
     bbp::niels_row* ptable = nullptr;      // [TAB_BASES * MSM_POS] affine cached 2^b * P_i, 128-byte limb rows (275 MB)

@@ -87,8 +87,12 @@ __device__ __forceinline__ fe load_fe40(const u8* p) {  // 10 limbs at a 16-byte
     return fe{{(i32)a.x, (i32)a.y, (i32)a.z, (i32)a.w, (i32)b.x, (i32)b.y, (i32)b.z, (i32)b.w, (i32)c.x, (i32)c.y}};
 }
 
-__device__ __forceinline__ row_regs load_row(const niels_row* __restrict__ tab, u32 entry) {
-    u32 row = min(entry & 0x7fffffffu, (u32)(TAB_BASES * MSM_POS - 1));
+__device__ __forceinline__ row_regs load_row(const niels_row* __restrict__ tab, u32 entry, u32* __restrict__ fault) {
+    u32 row = entry & 0x7fffffffu;
+    if (row > (u32)(TAB_BASES * MSM_POS - 1)) {  // never seen on sound scratch: clamp (no fault) AND say so (bbp_check_health)
+        row = (u32)(TAB_BASES * MSM_POS - 1);
+        atomicOr(fault, 1u);
+    }
 #ifdef BBP_EXP_ROWMASK  // experiment (wrong results): alias all gathers onto a cache-resident slice of the table
     row &= BBP_EXP_ROWMASK;
 #endif
@@ -244,7 +248,7 @@ __global__ __launch_bounds__(SORT_T) void k_msm_sort(const u32* __restrict__ sca
 template <int MODE>
 __global__ __launch_bounds__(MSM_T) __attribute__((amdgpu_waves_per_eu(BBP_MSM_WAVES, BBP_MSM_WAVES_MAX)))
 void k_msm_acc(const niels_row* __restrict__ ptable, const u32* __restrict__ sorted_all, const u32* __restrict__ cursor_all, u32 n /* sorted stride */,
-               ge* __restrict__ bsum_all, ge* __restrict__ psum_all, ge* __restrict__ out, const u32* __restrict__ n_active) {
+               ge* __restrict__ bsum_all, ge* __restrict__ psum_all, ge* __restrict__ out, const u32* __restrict__ n_active, u32* __restrict__ fault) {
     constexpr int K = msm_geom<MODE>::K, W = msm_geom<MODE>::W, G = K / MSM_T;
     __shared__ u32 cursor[K + 1];
     __shared__ u32 xch[GE_WORDS];
@@ -292,7 +296,7 @@ void k_msm_acc(const niels_row* __restrict__ ptable, const u32* __restrict__ sor
         // iteration ahead, so neither load is waited for before a full mixed addition (~1300 instructions) has run
         u32 ent_cur = sorted[c0];
         u32 ent_nxt = (c0 + 1 < c1) ? sorted[c0 + 1] : 0u;
-        row_regs row = load_row(ptable, ent_cur);
+        row_regs row = load_row(ptable, ent_cur, fault);
         for (u32 e = c0; e < c1; e++) {
             if (e == kend) {  // crossed into the next non-empty bucket
                 *dest = acc;
@@ -303,7 +307,7 @@ void k_msm_acc(const niels_row* __restrict__ ptable, const u32* __restrict__ sor
             const row_regs cur = row;
             const bool neg = ent_cur >> 31;
             ent_cur = ent_nxt;
-            if (e + 1 < c1) row = load_row(ptable, ent_cur);
+            if (e + 1 < c1) row = load_row(ptable, ent_cur, fault);
             if (e + 2 < c1) ent_nxt = sorted[e + 2];
             acc = ge_madd_row(acc, cur, neg);
         }
@@ -490,7 +494,7 @@ int32_t fold_generators_launch(bbp_ctx* ctx, uint32_t n_proofs, const sc* g_dev,
     }
     ScopedEvent ev(ctx, TAG_MSM, stream);
     hipLaunchKernelGGL(k_msm_acc<1>, dim3((u32)n_work), dim3(MSM_T), 0, stream, ctx->ptable, m.sorted, m.cursor, n_sub, m.bsum, m.psum,
-                       split > 1 ? m.tmp : out_dev, (const u32*)nullptr);
+                       split > 1 ? m.tmp : out_dev, (const u32*)nullptr, ctx->health);
     BBP_HIP_TRY(ctx, hipGetLastError());
     if (split > 1) {
         const u32 n_out = (u32)n_msm * FOLD_CLS;
@@ -534,7 +538,7 @@ int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* sc
     }
     ScopedEvent ev(ctx, TAG_MSM, stream);
     hipLaunchKernelGGL(k_msm_acc<0>, dim3(n_work), dim3(MSM_T), 0, stream, ctx->ptable, m.sorted, m.cursor, n_sub, m.bsum, m.psum,
-                       split > 1 ? m.tmp : out_points_dev, n_active_dev);
+                       split > 1 ? m.tmp : out_points_dev, n_active_dev, ctx->health);
     BBP_HIP_TRY(ctx, hipGetLastError());
     if (split > 1) {
         hipLaunchKernelGGL(k_msm_reduce, dim3((n_msm + 63) / 64), dim3(64), lds_token(ctx), stream, n_msm, split, 1u, m.tmp, out_points_dev);

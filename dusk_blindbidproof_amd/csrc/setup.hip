@@ -207,6 +207,8 @@ static int32_t init_body(int32_t device, bbp_ctx** out) {
     BBP_HIP_TRY(ctx, hipMalloc(&ctx->ptable, sizeof(niels_row) * (size_t)TAB_BASES * MSM_POS));
     BBP_HIP_TRY(ctx, hipMalloc(&ctx->comb, sizeof(niels_packed) * 2 * 64 * 8));
     BBP_HIP_TRY(ctx, hipMalloc(&ctx->mimc_c, sizeof(sc) * BBP_MIMC_ROUNDS));
+    BBP_HIP_TRY(ctx, hipMalloc(&ctx->health, sizeof(u32)));
+    BBP_HIP_TRY(ctx, hipMemset(ctx->health, 0, sizeof(u32)));
     BBP_HIP_TRY(ctx, hipMemcpyAsync(ctx->mimc_c, ctx->mimc_host.data(), 32 * BBP_MIMC_ROUNDS, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_derive_generators, dim3((BBP_NUM_BASES + 63) / 64), dim3(64), 0, ctx->stream, d_uniform, ctx->gens);
     BBP_HIP_TRY(ctx, hipGetLastError());
@@ -249,6 +251,7 @@ extern "C" void bbp_free(bbp_ctx* ctx) {
         if (sl.ev) (void)hipEventDestroy(sl.ev);
         if (sl.ev_in) (void)hipEventDestroy(sl.ev_in);
     }
+    if (ctx->health) (void)hipFree(ctx->health);
     for (auto& L : ctx->vl) {
         for (void* p : {L.misc.p, L.agg.p, L.agg_io.p, (void*)L.agg_count})
             if (p) (void)hipFree(p);
@@ -300,6 +303,19 @@ extern "C" const char* bbp_last_error(const bbp_ctx* ctx) {
 extern "C" void* bbp_context_stream(bbp_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 extern "C" void* bbp_context_copy_stream(bbp_ctx* ctx) { return ctx ? (void*)ctx->copy : nullptr; }
 extern "C" void* bbp_context_verify_stream(bbp_ctx* ctx, uint32_t lane) { return ctx && lane < bbp_ctx::VLANES ? (void*)ctx->vl[lane].stream : nullptr; }
+
+// Synchronises the device.  *flags: bit 0 = some MSM table gather since bbp_init was out of range and had to be clamped -- the
+// engine's scratch was corrupted and results computed since then may be wrong (never observed; the clamp exists so that such a
+// state cannot fault the GPU, this word so that it cannot pass silently).
+extern "C" int32_t bbp_check_health(bbp_ctx* ctx, uint32_t* flags) {
+    if (!ctx || !flags) return BBP_ERR_BAD_ARG;
+    return api_guard(ctx, [&]() -> int32_t {
+        BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+        BBP_HIP_TRY(ctx, hipDeviceSynchronize());
+        BBP_HIP_TRY(ctx, hipMemcpy(flags, ctx->health, sizeof(u32), hipMemcpyDeviceToHost));
+        return BBP_OK;
+    });
+}
 
 extern "C" int32_t bbp_get_generator(bbp_ctx* ctx, uint32_t index, uint8_t out32[32]) {
     if (!ctx || index >= BBP_NUM_BASES) return BBP_ERR_BAD_ARG;

@@ -174,6 +174,10 @@ int32_t bbp_batching_stats(bbp_ctx* ctx, uint64_t* n_calls, uint64_t* n_requests
  * barrier can be exercised without a GPU (BBP_FAULT_INJECT=compile in the environment makes the synthesis throw). */
 int32_t bbp_debug_compile_circuit(uint32_t N, uint32_t* n_mul, uint32_t* n_cons);
 
+/* Engine self-check (synchronises the device).  *flags bit 0: an MSM table gather was out of range since bbp_init and had to be
+ * clamped, i.e. engine scratch was corrupted (the one GPU fault of round 1 was such a state); 0 = healthy. */
+int32_t bbp_check_health(bbp_ctx* ctx, uint32_t* flags);
+
 /* Parity hook: the 32-scalar challenge block of proof `proof` of the LAST batch call of geometry (B, N):
  * y z u x w y^-1 t1..t6 tb1..tb6 t_x t_x~ e~ ... (MiscSlot order in csrc/batch.h), 32 x 32 bytes. */
 int32_t bbp_debug_challenges(bbp_ctx* ctx, uint32_t B, uint32_t N, uint32_t proof, uint8_t* out32x32);

@@ -45,7 +45,9 @@ def ctx(bbp):
         pass
     c = bbp.Context(0)  # raises loudly without a gfx950 device: no fallback
     yield c
+    flags = c.health()  # after the whole GPU session: no MSM gather was ever out of range (engine scratch never corrupted)
     c.close()
+    assert flags == 0, "engine health flags %#x" % flags
 
 
 @pytest.fixture(scope="session")
