@@ -27,11 +27,12 @@ namespace bbp {
 #ifndef BBP_MSM_WAVES
 #define BBP_MSM_WAVES 2
 #endif
-// The upper bound only steers the scheduler's register appetite: with (2, 2) it spreads over ~240 VGPRs, with (2, 4) it stays
-// near 214 without spilling.  Two such waves leave ~80 VGPRs per SIMD lane free, enough for one thin wave of another stream's
-// kernel (transcript, encode, scalar kernels: <= 64 VGPRs) to run BESIDE the MSM instead of between MSMs.
+// Since the fold phases moved into k_msm_fold (round 2) the accumulate kernel needs 156 VGPRs and no stack at all.  It is still
+// held to TWO waves per SIMD (2, 2): they leave 200 VGPRs per SIMD lane for the thin waves of the other streams' kernels
+// (transcript, encode, scalar, sort) to run BESIDE the MSM instead of between MSMs; allowing a third accumulate wave was
+// measured slower (18.2-18.3 k vs 18.5-18.6 k proofs/s; (2, 4), which lets occupancy float: 18.0-18.1 k).
 #ifndef BBP_MSM_WAVES_MAX
-#define BBP_MSM_WAVES_MAX 4
+#define BBP_MSM_WAVES_MAX 2
 #endif
 
 // -DBBP_MSM_PROF (experiments only): per-phase wall-clock (100 MHz) totals of lane 0 of every workgroup, printed every 16 launches
@@ -321,6 +322,43 @@ void k_msm_acc(const niels_row* __restrict__ ptable, const u32* __restrict__ sor
     __syncthreads();
     MSM_PROF_MARK(3);
 
+}
+
+// The cold half of an MSM as a kernel of its own: chunk-leading partial sums into their buckets (P), running-sum fold over each
+// lane's G buckets (D2), cross-lane fold (E).  It used to be the tail of k_msm_acc, where every point addition had to go through
+// ONE out-of-line copy (operands through the stack: 35 calls per lane and MSM, ~19 GB of scratch writes per 1024-proof batch) to
+// keep the hot loop's instruction-cache and register footprint; on its own the fold inlines its additions, and k_msm_acc ends
+// when its last table row is added.
+template <int MODE>
+__global__ __launch_bounds__(MSM_T) void k_msm_fold(const u32* __restrict__ cursor_all, ge* __restrict__ bsum_all, const ge* __restrict__ psum_all,
+                                                     ge* __restrict__ out, const u32* __restrict__ n_active) {
+    constexpr int K = msm_geom<MODE>::K, G = K / MSM_T;
+    __shared__ u32 cursor[K + 1];
+    __shared__ u32 xch[GE_WORDS];
+    const int tid = threadIdx.x;
+    if (n_active && blockIdx.x >= *n_active) return;
+    __builtin_amdgcn_s_setprio(2);
+    const size_t msm = blockIdx.x;
+    {
+        const u32* cur_in = cursor_all + msm * (size_t)(K + 1);
+        for (int k = tid; k <= K; k += MSM_T) cursor[k] = cur_in[k];
+    }
+    __syncthreads();
+    const u32 E = cursor[K];
+    ge* bsum = bsum_all + msm * (size_t)K;
+    const ge* psum = psum_all + msm * (size_t)MSM_T;
+    const u32 c0 = (u32)(((u64)tid * E) / MSM_T), c1 = (u32)(((u64)(tid + 1) * E) / MSM_T);
+    u32 k_first = 0;
+    bool inside = false;
+    if (c0 < c1) {  // the bucket this lane's chunk started in, as k_msm_acc found it
+        u32 lo = 1, hi = K;
+        while (lo < hi) {
+            u32 mid = (lo + hi) >> 1;
+            if (cursor[mid] > c0) hi = mid; else lo = mid + 1;
+        }
+        k_first = lo;
+        inside = cursor[lo - 1] < c0;
+    }
     // P. the chunk-leading partial sums go into their buckets, ONE addition per lane for the whole wave (folded into the
     //    bucket loop below they cost an addition in nearly every one of its G steps: some lane of the wave always had one).
     //    When several consecutive chunks start inside the same (heavy) bucket, the last of them adds the whole run.
@@ -343,19 +381,20 @@ void k_msm_acc(const niels_row* __restrict__ ptable, const u32* __restrict__ sor
 
     // D2. running-sum fold over this lane's G buckets (high to low), all lanes in lockstep
     ge running = ge_identity(), total = ge_identity();
+#pragma unroll 1
     for (int r = G; r >= 1; r--) {
         const u32 k = tid * G + r;
-        if (cursor[k] != cursor[k - 1]) ge_add_nc(running, running, bsum[k - 1]);
-        ge_add_nc(total, total, running);
+        if (cursor[k] != cursor[k - 1]) running = ge_add(running, bsum[k - 1]);
+        total = ge_add(total, running);
     }
-    MSM_PROF_MARK(4);
 
     if constexpr (MODE == 0) {
         // E. cross-lane fold: W = sum_k k S_k = sum_t total_t + G * sum_{t>=1} suffix_t, suffix_t = sum_{u>=t} running_u
         const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll 1
         for (int d = 1; d < 64; d <<= 1) {  // suffix scan inside each wavefront
             ge other = ge_shfl_down(running, d);
-            if (lane + d < 64) ge_add_nc(running, running, other);
+            if (lane + d < 64) running = ge_add(running, other);
         }
         if (MSM_T > 64) {
             if (tid == 64) xch_put(xch, running);  // = sum over the upper wavefront
@@ -371,9 +410,10 @@ void k_msm_acc(const niels_row* __restrict__ ptable, const u32* __restrict__ sor
             for (int i = 0; i < MSM_LOG_G; i++) ge_dbl_nc(s, s);
             ge_add_nc(x, x, s);
         }
+#pragma unroll 1
         for (int d = 32; d >= 1; d >>= 1) {
             ge other = ge_shfl_down(x, d);
-            if (lane < d) ge_add_nc(x, x, other);
+            if (lane < d) x = ge_add(x, other);
         }
         if (MSM_T > 64) {
             __syncthreads();
@@ -420,7 +460,6 @@ void k_msm_acc(const niels_row* __restrict__ ptable, const u32* __restrict__ sor
             out[msm * FOLD_CLS + (tid / LPC)] = accq;
         }
     }
-    MSM_PROF_MARK(5);
 }
 
 // sums the `split` partial results of every MSM: out[o] = sum_j tmp[((o / items) * split + j) * items + o % items]
@@ -496,6 +535,9 @@ int32_t fold_generators_launch(bbp_ctx* ctx, uint32_t n_proofs, const sc* g_dev,
     hipLaunchKernelGGL(k_msm_acc<1>, dim3((u32)n_work), dim3(MSM_T), 0, stream, ctx->ptable, m.sorted, m.cursor, n_sub, m.bsum, m.psum,
                        split > 1 ? m.tmp : out_dev, (const u32*)nullptr, ctx->health);
     BBP_HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_msm_fold<1>, dim3((u32)n_work), dim3(MSM_T), 0, stream, m.cursor, m.bsum, m.psum, split > 1 ? m.tmp : out_dev,
+                       (const u32*)nullptr);
+    BBP_HIP_TRY(ctx, hipGetLastError());
     if (split > 1) {
         const u32 n_out = (u32)n_msm * FOLD_CLS;
         hipLaunchKernelGGL(k_msm_reduce, dim3((n_out + 63) / 64), dim3(64), lds_token(ctx), stream, n_out, split, (u32)FOLD_CLS, m.tmp, out_dev);
@@ -539,6 +581,8 @@ int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* sc
     ScopedEvent ev(ctx, TAG_MSM, stream);
     hipLaunchKernelGGL(k_msm_acc<0>, dim3(n_work), dim3(MSM_T), 0, stream, ctx->ptable, m.sorted, m.cursor, n_sub, m.bsum, m.psum,
                        split > 1 ? m.tmp : out_points_dev, n_active_dev, ctx->health);
+    BBP_HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_msm_fold<0>, dim3(n_work), dim3(MSM_T), 0, stream, m.cursor, m.bsum, m.psum, split > 1 ? m.tmp : out_points_dev, n_active_dev);
     BBP_HIP_TRY(ctx, hipGetLastError());
     if (split > 1) {
         hipLaunchKernelGGL(k_msm_reduce, dim3((n_msm + 63) / 64), dim3(64), lds_token(ctx), stream, n_msm, split, 1u, m.tmp, out_points_dev);

@@ -10,7 +10,7 @@ PKG = os.path.join(ROOT, "dusk_blindbidproof_amd")
 name, flags = sys.argv[1], sys.argv[2:]
 objdir = os.path.join(PKG, "build", "variant_" + name)
 os.makedirs(objdir, exist_ok=True)
-srcs = sorted(f for f in os.listdir(os.path.join(PKG, "csrc")) if f.endswith(".hip"))
+srcs = sorted(f for f in os.listdir(os.path.join(PKG, "csrc")) if f.endswith((".hip", ".cpp")))
 procs, objs = [], []
 for s in srcs:
     o = os.path.join(objdir, s + ".o")
