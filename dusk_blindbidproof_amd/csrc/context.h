@@ -71,6 +71,7 @@ struct bbp_ctx {
     hipStream_t copy = nullptr;            // the caller's ingest stream (bbp_context_copy_stream): never used by the engine
     hipStream_t side2 = nullptr;           // second opening stream: batches too small to fill three heavy slices alternate between the two
     int varbase_lanes = 65536;             // lanes the verifier's variable-base kernel is launched with (BBP_VARBASE_LANES): ~1 wave per SIMD
+    int rotate_below = 1023;               // batches of at most this many proofs run their heavy stage unsliced on a rotating internal stream (BBP_ROTATE_BELOW, 0 = never)
     int dual_open_below = 1024;            // batches smaller than this open on alternating streams (BBP_DUAL_OPEN_BELOW, 0 = never)
     static constexpr int MAX_SLICES = 4;   // heavy-stage slices of one batch, one stream each (slice 0 = caller's stream)
     hipStream_t lane[MAX_SLICES] = {nullptr, nullptr, nullptr, nullptr};

@@ -475,10 +475,13 @@ __global__ void k_msm_reduce(u32 n_out, u32 split, u32 items, const ge* __restri
 
 // how many workgroups an MSM of n terms is cut into when the launch has only n_msm of them (fills the GPU for small batches)
 static u32 msm_split(u32 n_msm, u32 n_terms) {
-    // every sub-MSM pays the full bucket fold (phases D2, E), so splitting only pays while the GPU would otherwise be mostly
-    // empty: measured, B = 256 in three slices (170 MSMs per launch) is better off unsplit
-    if (n_msm >= 128) return 1;
-    u32 s = 512 / n_msm;
+    // every sub-MSM pays a bucket fold of its own (k_msm_fold), so splitting only pays while the GPU would otherwise be mostly
+    // empty.  BBP_MSM_SPLIT_BELOW (launches with fewer MSMs than this are split) / BBP_MSM_SPLIT_TARGET (into about this many
+    // workgroups) are read once.
+    static const u32 below = [] { const char* e = getenv("BBP_MSM_SPLIT_BELOW"); return e ? (u32)atoi(e) : 128u; }();
+    static const u32 target = [] { const char* e = getenv("BBP_MSM_SPLIT_TARGET"); return e ? (u32)atoi(e) : 512u; }();
+    if (n_msm >= below) return 1;
+    u32 s = target / n_msm;
     if (s > 16) s = 16;
     while (s > 1 && n_terms / s < 128) s--;
     return s ? s : 1;

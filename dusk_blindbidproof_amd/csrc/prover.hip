@@ -1248,6 +1248,21 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
     u32 slices = B >= 64u * (u32)ctx->slices ? (u32)ctx->slices : (B >= 128 ? 2u : 1u);
     if (dual && slices > 2) slices = 2;
     const size_t rec = BBP_R1CS_PROOF_BYTES + 32 * (size_t)m;
+    // Small batches: a heavy stage of a few hundred proofs is a chain of ~110 mostly latency-bound launches that leaves most of
+    // the GPU idle (256 MSM workgroups for 1024 slots), and on the caller's stream the chains of consecutive calls run one
+    // after the other: 31 ms per 256-proof call whatever else is tuned.  Such calls therefore run their heavy stage UNSLICED on
+    // one of the three internal slice streams in rotation (own scratch slot each, like slices): up to three calls' chains in
+    // flight; the caller's stream only waits for the result.
+    const bool rotate = dual && ctx->rotate_below > 0 && B <= (u32)ctx->rotate_below;
+    if (rotate) {
+        const int hs = 1 + (int)(call % (u32)(bbp_ctx::MAX_SLICES - 1));
+        hipStream_t ls = ctx->lane[hs];
+        BBP_HIP_TRY(ctx, hipStreamWaitEvent(ls, ctx->ev_open[par], 0));
+        if ((rc = prove_heavy(ctx, c, bd, B, out_dev, ls, hs, nullptr, ctx->ev_entry[par]))) return rc;
+        BBP_HIP_TRY(ctx, hipEventRecord(ctx->ev_join[hs], ls));
+        BBP_HIP_TRY(ctx, hipStreamWaitEvent(main_s, ctx->ev_join[hs], 0));
+        slices = 0;
+    }
     for (u32 i = 0; i < slices; i++) {
         const u32 first = (u32)(((u64)B * i) / slices), last = (u32)(((u64)B * (i + 1)) / slices);
         hipStream_t ls = i == 0 ? main_s : ctx->lane[i];

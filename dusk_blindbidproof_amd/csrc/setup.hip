@@ -167,6 +167,7 @@ static int32_t init_body(int32_t device, bbp_ctx** out) {
     if (const char* e = getenv("BBP_VERIFY_OVERLAP")) ctx->verify_overlap = atoi(e) != 0;
     if (const char* e = getenv("BBP_VERIFY_AGGREGATE")) ctx->verify_group = atoi(e) > 1 ? (uint32_t)atoi(e) : 0u;
     if (const char* e = getenv("BBP_DUAL_OPEN_BELOW")) ctx->dual_open_below = atoi(e);
+    if (const char* e = getenv("BBP_ROTATE_BELOW")) ctx->rotate_below = atoi(e);
     if (const char* e = getenv("BBP_VARBASE_LANES")) ctx->varbase_lanes = atoi(e) < 64 ? 64 : atoi(e);
     if (const char* e = getenv("BBP_TAIL_ROUND")) ctx->tail_round = atoi(e) == bbp::FOLD_ROUND ? bbp::FOLD_ROUND : 12;
     if (const char* e = getenv("BBP_STAGGER")) ctx->stagger_mode = atoi(e);

@@ -5,7 +5,7 @@ import dusk_blindbidproof_amd as bbp
 from bench import synth_scalars_device
 dev = torch.device("cuda", 0)
 ctx = bbp.Context(0)
-s = torch.cuda.current_stream().cuda_stream
+s = None  # the context's own stream (include/bbp.h BBP_STREAM_CONTEXT); callers synchronise the device
 n = 2049
 for B in (64, 256, 512, 1024, 2048, 4096):
     sc = synth_scalars_device(torch, B, n, 5, dev)

@@ -5,7 +5,7 @@ import dusk_blindbidproof_amd as bbp
 from bench import synth_scalars_device
 dev = torch.device("cuda", 0)
 ctx = bbp.Context(0)
-s = torch.cuda.current_stream().cuda_stream
+s = None  # the context's own stream (include/bbp.h BBP_STREAM_CONTEXT); callers synchronise the device
 B, n = 2048, 2049
 out = torch.zeros((B, 32), dtype=torch.uint8, device=dev)
 def run(sc, label):

@@ -20,7 +20,7 @@ if os.environ.get("USE_NCCL"):  # the real thing: a one-rank RCCL group, barrier
 torch.cuda.synchronize()
 ctx = bbp.Context(0)
 pw = make_workload("prove", ctx, bbp, torch, dev, 1024, 8, 1)
-s = torch.cuda.current_stream().cuda_stream
+s = None  # the context's own stream (include/bbp.h BBP_STREAM_CONTEXT); callers synchronise the device
 for _ in range(3): pw.step(s)
 torch.cuda.synchronize()
 t = time.perf_counter()

@@ -9,7 +9,7 @@ from bench_workloads import make_workload
 
 dev = torch.device("cuda", 0)
 ctx = bbp.Context(0)
-s = torch.cuda.current_stream().cuda_stream
+s = None  # the context's own stream (include/bbp.h BBP_STREAM_CONTEXT); callers synchronise the device
 sizes = [int(x) for x in sys.argv[1:]] or [64, 128, 256, 384, 512, 768, 1024]
 for B in sizes:
     wls = [make_workload("prove", ctx, bbp, torch, dev, B, 8, seed) for seed in (1, 2, 3)]

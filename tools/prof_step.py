@@ -14,7 +14,7 @@ name = sys.argv[3] if len(sys.argv) > 3 else "prove"
 dev = torch.device("cuda", 0)
 ctx = bbp.Context(0)
 wl = make_workload(name, ctx, bbp, torch, dev, B, N, 1)
-s = torch.cuda.current_stream().cuda_stream
+s = None  # the context's own stream (include/bbp.h BBP_STREAM_CONTEXT); callers synchronise the device
 wl.step(s)
 torch.cuda.synchronize()
 ctx.set_profiling(True)

@@ -9,7 +9,7 @@ dev = torch.device("cuda", 0)
 ctx = bbp.Context(0)
 pw = make_workload("prove", ctx, bbp, torch, dev, 1024, 8, 1)
 vw = VerifyWorkload(ctx, bbp, torch, dev, 1024, 8, 1, prove_wl=pw)
-s = torch.cuda.current_stream().cuda_stream
+s = None  # the context's own stream (include/bbp.h BBP_STREAM_CONTEXT); callers synchronise the device
 for mode in ("prove", "verify", "both"):
     for _ in range(3):
         if mode != "verify": pw.step(s)

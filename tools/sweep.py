@@ -8,7 +8,7 @@ from bench_workloads import make_workload, VerifyWorkload
 
 dev = torch.device("cuda", 0)
 ctx = bbp.Context(0)
-s = torch.cuda.current_stream().cuda_stream
+s = None  # the context's own stream (include/bbp.h BBP_STREAM_CONTEXT); callers synchronise the device
 for B, N in ((1024, 1), (1024, 8), (1024, 64), (1024, 202), (256, 8), (512, 8), (2048, 8), (4096, 8)):
     pw = make_workload("prove", ctx, bbp, torch, dev, B, N, 1)
     vw = VerifyWorkload(ctx, bbp, torch, dev, B, N, 1, prove_wl=pw)

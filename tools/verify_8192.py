@@ -7,7 +7,7 @@ import dusk_blindbidproof_amd as bbp
 from bench_workloads import make_workload, VerifyWorkload
 dev = torch.device("cuda", 0)
 ctx = bbp.Context(0)
-s = torch.cuda.current_stream().cuda_stream
+s = None  # the context's own stream (include/bbp.h BBP_STREAM_CONTEXT); callers synchronise the device
 pw = make_workload("prove", ctx, bbp, torch, dev, 1024, 8, 1)
 pw.step(s); torch.cuda.synchronize()
 rec = pw.rec
