@@ -139,9 +139,9 @@ struct bbp_ctx {
     bbp::DevBuf scal, idx, sorted, pts, enc, batch[PROVE_BUFS + VLANES], io_in, io_out, io_ent, raw[2];  // batch[3 + lane]: the verifier lanes'; raw[i]: draw buffer of opening stream i
     static constexpr int VERIFY_SLOT = MAX_SLICES;  // MSM scratch slots of the verifier lanes: VERIFY_SLOT + lane
     bbp::DevBuf slice_sorted[MAX_SLICES + VLANES], slice_pts[MAX_SLICES + VLANES], slice_fold[MAX_SLICES], slice_vtab[MAX_SLICES];  // per-slice MSM scratch (slice 0 uses sorted / pts)
-    // Host-pointer batch calls stage through one of two slots (device in / entropy / out + a pinned host mirror of the results):
+    // Host-pointer batch calls stage through one of three slots (device in / entropy / out + a pinned host mirror of the results):
     // a call holds the context lock only while it ENQUEUES; it waits for its results on the slot's event with the lock released,
-    // so a second host thread can enqueue the next batch meanwhile and the engine's cross-call pipeline (opening stage of call
+    // so other host threads can enqueue the next batches meanwhile and the engine's cross-call pipeline (opening stage of call
     // k+1 under the MSM stage of call k) also works for bbp_prove_batch / bbp_prove / the UDS server (capi_prove.hip).
     struct IoSlot {
         bbp::DevBuf in, ent, out;
@@ -150,7 +150,7 @@ struct bbp_ctx {
         hipEvent_t ev = nullptr, ev_in = nullptr;
         bool busy = false;
     };
-    static constexpr int IO_SLOTS = 2;
+    static constexpr int IO_SLOTS = 3;
     IoSlot io[IO_SLOTS];
     std::mutex io_mu;
     std::condition_variable io_cv;

@@ -59,7 +59,8 @@ class Combiner {
     std::mutex mu_;
     std::condition_variable cv_window_;  // arrivals -> the leader that sits in its batching window
     std::deque<Request*> q_;
-    static constexpr int MAX_LEADERS = 2;
+    static constexpr int MAX_LEADERS = 2;  // three (as many as there are staging slots) fragments closed-loop load into more, smaller batches:
+                                           // measured through the UDS server 14.7 k -> 11.5 k proofs/s prove-only, 8.2 k -> 7.1 k ops/s at 2048 connections
     int leaders_ = 0;         // callers currently designated to run (or running) a batch
     void designate_locked();  // hand free leader slots to queued callers
     uint32_t window_us_ = 0, max_batch_ = 4096, stagger_us_ = 0;
