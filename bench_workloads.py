@@ -5,7 +5,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 TAG_NAMES = {1: "k_msm_acc", 11: "k_msm_sort", 2: "k_encode", 3: "k_witness_head", 4: "k_open_serial(witness+rng)", 5: "k_poly/powers/flatten", 6: "k_ipa_round", 7: "k_commit",
-             8: "k_transcript", 9: "k_vscalars", 10: "k_varbase/tail"}
+             8: "k_transcript", 9: "k_vscalars", 10: "k_varbase/tail", 12: "k_msm_fold"}
 L = 2**252 + 27742317777372353535851937790883648493
 
 

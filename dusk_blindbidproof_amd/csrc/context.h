@@ -190,7 +190,7 @@ inline int32_t dev_reserve(bbp_ctx* ctx, DevBuf& b, size_t bytes) {
 }
 
 enum { TAG_MSM = 1, TAG_ENCODE = 2, TAG_WITNESS = 3, TAG_RNG = 4, TAG_POLY = 5, TAG_IPA_SCALARS = 6, TAG_COMMIT = 7,
-       TAG_TRANSCRIPT = 8, TAG_VERIFY_SCALARS = 9, TAG_VARBASE = 10, TAG_MSM_SORT = 11 };
+       TAG_TRANSCRIPT = 8, TAG_VERIFY_SCALARS = 9, TAG_VARBASE = 10, TAG_MSM_SORT = 11, TAG_MSM_FOLD = 12 };
 
 struct ScopedEvent {  // records start now, stop at scope exit, when profiling is on
     bbp_ctx* ctx;

@@ -534,10 +534,13 @@ int32_t fold_generators_launch(bbp_ctx* ctx, uint32_t n_proofs, const sc* g_dev,
                            m.sorted, m.cursor, (const u32*)nullptr, (const u32*)nullptr);
         BBP_HIP_TRY(ctx, hipGetLastError());
     }
-    ScopedEvent ev(ctx, TAG_MSM, stream);
-    hipLaunchKernelGGL(k_msm_acc<1>, dim3((u32)n_work), dim3(MSM_T), 0, stream, ctx->ptable, m.sorted, m.cursor, n_sub, m.bsum, m.psum,
-                       split > 1 ? m.tmp : out_dev, (const u32*)nullptr, ctx->health);
-    BBP_HIP_TRY(ctx, hipGetLastError());
+    {
+        ScopedEvent ev(ctx, TAG_MSM, stream);
+        hipLaunchKernelGGL(k_msm_acc<1>, dim3((u32)n_work), dim3(MSM_T), 0, stream, ctx->ptable, m.sorted, m.cursor, n_sub, m.bsum, m.psum,
+                           split > 1 ? m.tmp : out_dev, (const u32*)nullptr, ctx->health);
+        BBP_HIP_TRY(ctx, hipGetLastError());
+    }
+    ScopedEvent evf(ctx, TAG_MSM_FOLD, stream);
     hipLaunchKernelGGL(k_msm_fold<1>, dim3((u32)n_work), dim3(MSM_T), 0, stream, m.cursor, m.bsum, m.psum, split > 1 ? m.tmp : out_dev,
                        (const u32*)nullptr);
     BBP_HIP_TRY(ctx, hipGetLastError());
@@ -581,10 +584,13 @@ int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* sc
                            m.sorted, m.cursor, msm_map_dev, n_active_dev);
         BBP_HIP_TRY(ctx, hipGetLastError());
     }
-    ScopedEvent ev(ctx, TAG_MSM, stream);
-    hipLaunchKernelGGL(k_msm_acc<0>, dim3(n_work), dim3(MSM_T), 0, stream, ctx->ptable, m.sorted, m.cursor, n_sub, m.bsum, m.psum,
-                       split > 1 ? m.tmp : out_points_dev, n_active_dev, ctx->health);
-    BBP_HIP_TRY(ctx, hipGetLastError());
+    {
+        ScopedEvent ev(ctx, TAG_MSM, stream);
+        hipLaunchKernelGGL(k_msm_acc<0>, dim3(n_work), dim3(MSM_T), 0, stream, ctx->ptable, m.sorted, m.cursor, n_sub, m.bsum, m.psum,
+                           split > 1 ? m.tmp : out_points_dev, n_active_dev, ctx->health);
+        BBP_HIP_TRY(ctx, hipGetLastError());
+    }
+    ScopedEvent evf(ctx, TAG_MSM_FOLD, stream);
     hipLaunchKernelGGL(k_msm_fold<0>, dim3(n_work), dim3(MSM_T), 0, stream, m.cursor, m.bsum, m.psum, split > 1 ? m.tmp : out_points_dev, n_active_dev);
     BBP_HIP_TRY(ctx, hipGetLastError());
     if (split > 1) {

@@ -188,7 +188,7 @@ int32_t bbp_debug_challenges(bbp_ctx* ctx, uint32_t B, uint32_t N, uint32_t proo
 int32_t bbp_ubench(bbp_ctx* ctx, int32_t kind, uint32_t blocks, uint32_t iters, double* ops_per_sec);
 
 /* Per-kernel device timings: with profiling on, every kernel launch is bracketed by HIP events on its launch stream.
- * bbp_last_timings synchronises, drains them as (tag, microseconds) float pairs (tags: 1 = MSM accumulate kernel, 11 = MSM sort kernel, 2 = encode, ...)
+ * bbp_last_timings synchronises, drains them as (tag, microseconds) float pairs (tags: 1 = MSM accumulate kernel, 11 = MSM sort kernel, 12 = MSM fold kernel, 2 = encode, ...)
  * and reports the number of floats written in *n. */
 int32_t bbp_set_profiling(bbp_ctx* ctx, int32_t on);
 int32_t bbp_last_timings(bbp_ctx* ctx, float* out, uint32_t cap, uint32_t* n);
