@@ -8,6 +8,18 @@
 
 namespace bbp {
 
+// cv.wait_until on the steady clock is pthread_cond_clockwait, which GCC 11's ThreadSanitizer runtime does not intercept (it then
+// believes the mutex stays locked across the wait and reports phantom double locks and races): the sanitizer build of the tests
+// (tests/combiner_tsan.cpp) waits on the system clock instead, the product on the steady one.
+static std::cv_status wait_until_steady(std::condition_variable& cv, std::unique_lock<std::mutex>& lk, std::chrono::steady_clock::time_point deadline) {
+#if defined(__SANITIZE_THREAD__)
+    const auto left = deadline - std::chrono::steady_clock::now();
+    return cv.wait_until(lk, std::chrono::system_clock::now() + std::chrono::duration_cast<std::chrono::system_clock::duration>(left));
+#else
+    return cv.wait_until(lk, deadline);
+#endif
+}
+
 void Combiner::configure(uint32_t window_us, uint32_t max_batch) {
     std::lock_guard<std::mutex> lk(mu_);
     window_us_ = window_us;
@@ -64,7 +76,7 @@ int32_t Combiner::submit(bbp_ctx* ctx, Request& r) {
         // Optional window: give concurrent callers a moment to join this batch.
         if (window_us_) {
             const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(window_us_);
-            while (q_.size() < max_batch_ && cv_window_.wait_until(lk, deadline) != std::cv_status::timeout) {
+            while (q_.size() < max_batch_ && wait_until_steady(cv_window_, lk, deadline) != std::cv_status::timeout) {
             }
             if (q_.empty()) {  // the other leader took everything meanwhile
                 resign();
@@ -75,7 +87,7 @@ int32_t Combiner::submit(bbp_ctx* ctx, Request& r) {
         if (stagger_us_ && inflight_ > 0 && q_.front()->kind == 0) {  // a PROVE batch is on the device and this would be another:
             // let it grow until that one's opening stage is over (verifications have no such stage and never wait here)
             const auto start_at = last_start_ + std::chrono::microseconds(stagger_us_);
-            while (inflight_ > 0 && q_.size() < max_batch_ && cv_window_.wait_until(lk, start_at) != std::cv_status::timeout) {
+            while (inflight_ > 0 && q_.size() < max_batch_ && wait_until_steady(cv_window_, lk, start_at) != std::cv_status::timeout) {
             }
             if (q_.empty()) {
                 resign();

@@ -184,6 +184,16 @@ def test_combiner_keeps_two_batches_in_flight(built):
     assert L.stub_max_concurrency(h) == 2
 
 
+def test_combiner_under_thread_sanitizer(built):
+    """csrc/submit.cpp compiled with -fsanitize=thread behind a stand-in engine: 48 threads, three request classes, prove and
+    verify mixed, a batching window and a stagger -- every answer right, one class per batch, max_batch respected, at most two
+    batches in flight, and no data race reported by the sanitizer."""
+    p = subprocess.run([built.build_combiner_tsan()], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr[-3000:]
+    assert "WARNING: ThreadSanitizer" not in p.stderr, p.stderr[-3000:]
+    assert "wrong 0, bad batches 0" in p.stdout, p.stdout
+
+
 def test_connections_are_dealt_over_several_device_contexts(built):
     """--devices a,b,..: one engine context per GPU, connections round-robin (independent bids: no cross-GPU traffic on this
     path).  With the stub both contexts are fakes; the plumbing -- two contexts created, both used, statistics summed -- is real."""
