@@ -98,6 +98,33 @@ def test_prove_errors_write_nothing(server):
     assert uc.prove(server["path"], s7, pub, toggle) is not None               # and the server is still serving
 
 
+def test_slow_partial_and_abandoned_clients(server):
+    """A frame that trickles in a few bytes at a time is served; clients that hang up mid-header, mid-payload or right after
+    sending (never reading the reply) cost the server nothing: it keeps answering everyone else."""
+    s7, pub, toggle = _bid(77, 4)
+    frame = uc.prove_request(s7, pub, toggle)
+    c = uc.Conn(server["path"])
+    for i in range(0, len(frame), 37):
+        c.send(frame[i:i + 37])
+        time.sleep(0.002)
+    blob = c.recv_frame()
+    assert blob is not None and len(uc.decode_proof(blob)[2]) == 4
+    c.close()
+    for cut in (1, 2, 50, len(frame) - 1):                      # hang up mid-header / mid-payload
+        c = uc.Conn(server["path"])
+        c.send(frame[:cut])
+        c.close()
+    for _ in range(20):                                          # fire and forget: the reply has nowhere to go
+        c = uc.Conn(server["path"])
+        c.send(frame)
+        c.close()
+    idle = [uc.Conn(server["path"]) for _ in range(50)]         # connected, silent
+    assert uc.verify(server["path"], blob, s7[128:160], s7[160:192], s7[192:224], pub) == b"\x01"
+    for c in idle:
+        c.close()
+    assert uc.prove(server["path"], s7, pub, toggle) is not None
+
+
 def test_one_connection_may_carry_several_requests(server):
     s7, pub, toggle = _bid(21, 2)
     c = uc.Conn(server["path"])
