@@ -83,10 +83,10 @@ struct bbp_ctx {
     // by the CU's LDS crossbar (18 ds_bpermute per round): with ONE wavefront (two proofs) per CU a permutation takes a third of
     // the single-lane time -- a single proof 44 -> 25 ms, 256 proofs 55 -> 41 ms -- but 1024 proofs would need 512 CUs' worth of
     // crossbar, and the single-lane chain hides under the previous batch's MSM stage anyway.  Auto (-1): cooperative for batches
-    // of at most rng_coop_below proofs.  BBP_RNG_COOP=0 / 1 forces, BBP_RNG_COOP_BELOW, BBP_RNG_BLOCK tune.
+    // of at most rng_coop_below proofs (768; with four wavefronts per CU a 512-proof chain takes ~15 ms on 64 CUs).  BBP_RNG_COOP=0 / 1 forces, BBP_RNG_COOP_BELOW, BBP_RNG_BLOCK tune.
     int rng_coop = -1;
-    int rng_coop_below = 256;
-    int rng_block = 64;           // threads per workgroup of k_open_bulk: 64 = one wavefront (two proofs) per reserved CU
+    int rng_coop_below = 768;
+    int rng_block = 0;            // threads per workgroup of k_open_bulk (BBP_RNG_BLOCK); 0 = by batch size: 64 (one wavefront = two proofs per reserved CU) up to 128 proofs, 128 up to 256, 256 above
     int serial_block = 64;        // threads per workgroup of those kernels: 256 = one serial wave per SIMD of the reserved CU (BBP_SERIAL_BLOCK)
     std::map<const void*, int> serial_attr;
     int stagger_mode = 0;  // 0: slices start together, 1: next slice starts after this slice's first MSM, 3: after its third (BBP_STAGGER)

@@ -1233,7 +1233,10 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
             // bulk: 32 lanes per proof for the draw chain + one lane per proof for the witness, in one launch of `cblk`-thread
             // workgroups that keep their CU to themselves (LDS hog): cblk / 32 proofs per rng workgroup
             if ((rc = serial_lds_bytes(ctx, (const void*)k_open_bulk))) return rc;
-            const u32 cblk = (u32)ctx->rng_block;
+            // workgroup size: one wavefront (two proofs) per reserved CU is the fastest chain, but at 256 proofs that reserves 128 CUs
+            // under the other in-flight calls' heavy stages; two wavefronts per CU there (measured 11.3 k -> 12.5 k proofs/s back to back),
+            // four above 256 proofs (384: 12.8 k -> 14.8 k, 512: 14.6 k -> 16.5 k against the single-lane chain)
+            const u32 cblk = ctx->rng_block > 0 ? (u32)ctx->rng_block : (B <= 128 ? 64u : B <= 256 ? 128u : 256u);
             const u32 nb_rng = cdiv(B * 32, cblk), nb_wit = cdiv(B, cblk);
             LAUNCH_LDS(ctx, TAG_RNG, k_open_bulk, nb_rng + nb_wit, cblk, hog, s, B, nb_rng, n1, 2 + 2 * n1, bd.rng, (u32*)ctx->raw[sidx].p, m,
                        c.n_cst, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v, bd.ai1, bd.ao1);
