@@ -188,6 +188,42 @@ def test_aggregated_verification_is_stream_ordered(ctx, bbp):
         assert {i for i, v in enumerate(got) if v != 0} == bad, k
 
 
+def test_two_verifier_lanes_share_nothing(ctx, bbp):
+    """bbp_context_verify_stream(0 / 1): calls on the two lanes' streams run concurrently on the device (own batch buffer, scratch,
+    MSM scratch slot and aggregation buffers each).  Eight calls alternate lanes with no synchronisation in between, per-proof and
+    aggregated mixed, every call over a different corruption pattern and batch size: each must report exactly its own pattern."""
+    import torch
+    dev = torch.device("cuda", 0)
+    N, distinct = 8, 40
+    ins, ents, vins = _synth_batch(ctx, distinct, N, seed=271828)
+    out, st = ctx.prove_batch(distinct, N, b"".join(ins), b"".join(ents))
+    assert st == [0] * distinct
+    rs_ = bbp.record_size(N)
+    lanes = [torch.cuda.ExternalStream(ctx.verify_stream(i), device=dev) for i in range(2)]
+    assert lanes[0].cuda_stream != lanes[1].cuda_stream
+    calls = []
+    for k in range(8):
+        B = (300, 517, 64, 1000)[k % 4]
+        bad = {(7 * k + 11 * j) % B for j in range(k)}          # call 0 is all honest
+        rows = [bytearray(out[(i % distinct) * rs_:(i % distinct + 1) * rs_] + b"".join(vins[i % distinct])) for i in range(B)]
+        for i in bad:
+            rows[i][1 + 32 * 3 + (i % 200)] ^= 0x40
+        d_in = torch.frombuffer(bytearray(b"".join(bytes(r) for r in rows)), dtype=torch.uint8).to(dev)
+        calls.append((B, bad, d_in, torch.zeros(32 * B, dtype=torch.uint8, device=dev), torch.full((B,), -1, dtype=torch.int32, device=dev)))
+    torch.cuda.synchronize()
+    for k, (B, bad, d_in, d_ent, d_st) in enumerate(calls):
+        s = lanes[k & 1].cuda_stream
+        if k % 3 == 2:
+            ctx.verify_batch_aggregated_dev(B, N, d_in.data_ptr(), d_ent.data_ptr(), d_st.data_ptr(), 16, s, want_count=False)
+        else:
+            ctx.verify_batch_dev(B, N, d_in.data_ptr(), d_ent.data_ptr(), d_st.data_ptr(), s)
+    torch.cuda.synchronize()
+    for k, (B, bad, _, _, d_st) in enumerate(calls):
+        got = d_st.cpu().tolist()
+        assert {i for i, v in enumerate(got) if v != 0} == bad, k
+        assert all(v in (0, 1, 3) for v in got), k
+
+
 # ---- a9: Scalar::from_bits semantics on the device path ------------------------------------------------------------------------
 NONCANON = [L, L + 1, 2**255 - 1, 2**255 + 12345, 2**256 - 1, 2**255 + L + 7]
 
