@@ -209,14 +209,14 @@ extern "C" int32_t bbp_prepare_bids_dev(bbp_ctx* ctx, uint32_t B, uint32_t N, co
     });
 }
 
-// ---- host-pointer batch calls: two staging slots, lock held only while enqueueing (context.h IoSlot) ---------------------------
+// ---- host-pointer batch calls: three staging slots, lock held only while enqueueing (context.h IoSlot) ---------------------------
 namespace bbp {
 struct SlotLease {
     bbp_ctx* ctx;
     bbp_ctx::IoSlot* sl;
     explicit SlotLease(bbp_ctx* c) : ctx(c) {
         std::unique_lock<std::mutex> lk(c->io_mu);
-        const uint32_t want = c->io_next++ % bbp_ctx::IO_SLOTS;  // strict alternation keeps two consecutive calls on different slots
+        const uint32_t want = c->io_next++ % bbp_ctx::IO_SLOTS;  // strict rotation keeps consecutive calls on different slots
         c->io_cv.wait(lk, [&] { return !c->io[want].busy; });
         sl = &c->io[want];
         sl->busy = true;
@@ -229,14 +229,14 @@ struct SlotLease {
         ctx->io_cv.notify_all();
     }
 };
-// Wait for a slot's results WITHOUT parking inside the HIP runtime: a thread blocked in hipEventSynchronize / hipStreamSynchronize
-// keeps other threads' launches on that stream waiting (measured: two threads calling bbp_prove_batch got no overlap at all,
-// 90 ms per 1024-proof batch either way), which is exactly what the second staging slot is there to allow.  Polling the event
-// leaves the runtime free between polls; BBP_WAIT_POLL_US (default 100) is the sleep between them.
+// Waiting for a slot's event with the context lock released.  hipEventSynchronize by default; BBP_WAIT_POLL_US=n polls
+// hipEventQuery every n microseconds instead (no measurable difference on MI355X / ROCm 7.2 once the copies were kept out of
+// the DMA queues' way -- see fetch_results -- 18.7 k vs 18.6 k proofs/s from two threads; kept as a knob for runtimes where a
+// thread parked in the runtime gets in the way of other threads' launches).
 static hipError_t wait_event_polling(hipEvent_t ev) {
     static const int poll_us = [] {
         const char* e = getenv("BBP_WAIT_POLL_US");
-        return e ? atoi(e) : 100;
+        return e ? atoi(e) : 0;
     }();
     if (poll_us <= 0) return hipEventSynchronize(ev);
     for (;;) {
@@ -262,20 +262,12 @@ static int32_t pinned_reserve(bbp_ctx* ctx, void*& p, size_t& cap, size_t bytes)
 static int32_t upload_inputs(bbp_ctx* ctx, bbp_ctx::IoSlot& sl, const uint8_t* a, size_t na, const uint8_t* b, size_t nb) {
     int32_t rc;
     if ((rc = dev_reserve(ctx, sl.in, na)) || (rc = dev_reserve(ctx, sl.ent, nb)) || (rc = pinned_reserve(ctx, sl.h_in, sl.h_in_cap, na + nb))) return rc;
-    static const bool trace = getenv("BBP_TRACE") != nullptr;
-    auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double t0 = now_ms();
     memcpy(sl.h_in, a, na);
     memcpy((uint8_t*)sl.h_in + na, b, nb);
-    const double t1 = now_ms();
     BBP_HIP_TRY(ctx, hipMemcpyAsync(sl.in.p, sl.h_in, na, hipMemcpyHostToDevice, ctx->copy));
-    const double t2 = now_ms();
     BBP_HIP_TRY(ctx, hipMemcpyAsync(sl.ent.p, (uint8_t*)sl.h_in + na, nb, hipMemcpyHostToDevice, ctx->copy));
-    const double t3 = now_ms();
     BBP_HIP_TRY(ctx, hipEventRecord(sl.ev_in, ctx->copy));
-    const double t4 = now_ms();
     BBP_HIP_TRY(ctx, wait_event_polling(sl.ev_in));
-    if (trace) fprintf(stderr, "[bbp trace] upload: memcpy %.2f, copy1 %.2f, copy2 %.2f, record %.2f, wait %.2f ms\n", t1 - t0, t2 - t1, t3 - t2, t4 - t3, now_ms() - t4);
     return BBP_OK;
 }
 // Second half of a host-pointer call, context lock NOT held: wait for the slot's compute to finish, THEN copy the results down.
