@@ -26,6 +26,15 @@ constexpr int MSM_K = 1 << (MSM_NAF - 2); // 1024 buckets: bucket k holds the di
 #define BBP_MSM_T 128
 #endif
 constexpr int MSM_T = BBP_MSM_T;          // lanes of the accumulate workgroup: 128 (2 wavefronts; -DBBP_MSM_T=64 for experiments)
+#ifndef BBP_ACC_T
+#define BBP_ACC_T 256
+#endif
+// lanes of k_msm_acc = equal chunks the sorted entries are cut into (k_msm_fold keeps MSM_T lanes).  Since the fold moved out the
+// accumulate kernel is nothing but the chunk loop, and 256 lanes (four wavefronts) per MSM fill the machine better than 128: a
+// third-of-a-batch launch is 682 MSMs = 2728 wavefronts for 2048 resident slots instead of 1364 (measured 18.2-18.4 k -> 19.0-19.6 k
+// proofs/s; 384 lanes 17.0 k, 512 lanes 18.2 k; more than two waves per SIMD with 256 lanes 18.5-18.8 k)
+constexpr int ACC_T = BBP_ACC_T;
+static_assert(ACC_T % MSM_T == 0, "the fold kernel deals the accumulate kernel's chunks to its lanes");
 constexpr int MSM_G = MSM_K / MSM_T;      // consecutive buckets per lane (8)
 constexpr int MSM_LOG_G = MSM_T == 128 ? 3 : 4;
 static_assert(MSM_T == 128 || MSM_T == 64, "the cross-lane fold is written for one or two wavefronts");

@@ -247,10 +247,10 @@ __global__ __launch_bounds__(SORT_T) void k_msm_sort(const u32* __restrict__ sca
 }
 
 template <int MODE>
-__global__ __launch_bounds__(MSM_T) __attribute__((amdgpu_waves_per_eu(BBP_MSM_WAVES, BBP_MSM_WAVES_MAX)))
+__global__ __launch_bounds__(ACC_T) __attribute__((amdgpu_waves_per_eu(BBP_MSM_WAVES, BBP_MSM_WAVES_MAX)))
 void k_msm_acc(const niels_row* __restrict__ ptable, const u32* __restrict__ sorted_all, const u32* __restrict__ cursor_all, u32 n /* sorted stride */,
                ge* __restrict__ bsum_all, ge* __restrict__ psum_all, ge* __restrict__ out, const u32* __restrict__ n_active, u32* __restrict__ fault) {
-    constexpr int K = msm_geom<MODE>::K, W = msm_geom<MODE>::W, G = K / MSM_T;
+    constexpr int K = msm_geom<MODE>::K, W = msm_geom<MODE>::W, G = K / MSM_T;  // (G: unused here since the fold moved out)
     __shared__ u32 cursor[K + 1];
     __shared__ u32 xch[GE_WORDS];
     const int tid = threadIdx.x;
@@ -263,7 +263,7 @@ void k_msm_acc(const niels_row* __restrict__ ptable, const u32* __restrict__ sor
     MSM_PROF_BEGIN();
     {
         const u32* cur_in = cursor_all + msm * (size_t)(K + 1);
-        for (int k = tid; k <= K; k += MSM_T) cursor[k] = cur_in[k];
+        for (int k = tid; k <= K; k += ACC_T) cursor[k] = cur_in[k];
     }
     __syncthreads();
     MSM_PROF_MARK(1);
@@ -274,8 +274,8 @@ void k_msm_acc(const niels_row* __restrict__ ptable, const u32* __restrict__ sor
     //     every other bucket (or bucket head) it meets goes to bsum[bucket].
     const u32 E = cursor[K];  // may be 0 (an empty sub-MSM): then no chunk has entries and no bucket is non-empty, E never divides
     ge* bsum = bsum_all + msm * (size_t)K;               // [K] bucket k at index k-1
-    ge* psum = psum_all + msm * (size_t)MSM_T;           // [T]
-    const u32 c0 = (u32)(((u64)tid * E) / MSM_T), c1 = (u32)(((u64)(tid + 1) * E) / MSM_T);
+    ge* psum = psum_all + msm * (size_t)ACC_T;           // [ACC_T]
+    const u32 c0 = (u32)(((u64)tid * E) / ACC_T), c1 = (u32)(((u64)(tid + 1) * E) / ACC_T);
 #ifdef BBP_MSM_PROF
     const unsigned long long clk0 = clock64();
 #endif
@@ -346,28 +346,25 @@ __global__ __launch_bounds__(MSM_T) void k_msm_fold(const u32* __restrict__ curs
     __syncthreads();
     const u32 E = cursor[K];
     ge* bsum = bsum_all + msm * (size_t)K;
-    const ge* psum = psum_all + msm * (size_t)MSM_T;
-    const u32 c0 = (u32)(((u64)tid * E) / MSM_T), c1 = (u32)(((u64)(tid + 1) * E) / MSM_T);
-    u32 k_first = 0;
-    bool inside = false;
-    if (c0 < c1) {  // the bucket this lane's chunk started in, as k_msm_acc found it
-        u32 lo = 1, hi = K;
+    const ge* psum = psum_all + msm * (size_t)ACC_T;
+    // P. the chunk-leading partial sums of the accumulate kernel's ACC_T chunks go into their buckets.  A chunk that started
+    //    strictly inside a bucket left that leading partial in psum[chunk]; when several consecutive chunks start inside the same
+    //    (heavy) bucket, the LAST of them adds the whole run -- one writer per bucket.  Chunks are dealt to the MSM_T lanes.
+    for (u32 ch = tid; ch < (u32)ACC_T; ch += MSM_T) {
+        const u32 c0 = (u32)(((u64)ch * E) / ACC_T), c1 = (u32)(((u64)(ch + 1) * E) / ACC_T);
+        if (c0 >= c1) continue;
+        u32 lo = 1, hi = K;  // the bucket this chunk started in, as k_msm_acc found it
         while (lo < hi) {
             u32 mid = (lo + hi) >> 1;
             if (cursor[mid] > c0) hi = mid; else lo = mid + 1;
         }
-        k_first = lo;
-        inside = cursor[lo - 1] < c0;
-    }
-    // P. the chunk-leading partial sums go into their buckets, ONE addition per lane for the whole wave (folded into the
-    //    bucket loop below they cost an addition in nearly every one of its G steps: some lane of the wave always had one).
-    //    When several consecutive chunks start inside the same (heavy) bucket, the last of them adds the whole run.
-    {
+        const u32 k_first = lo;
+        const bool inside = cursor[lo - 1] < c0;
         const bool last_of_run = inside && !(c1 < E && c1 > cursor[k_first - 1] && c1 < cursor[k_first]);
         if (last_of_run) {
-            ge part = psum[tid];
-            for (int u = tid - 1; u >= 0; u--) {  // earlier chunks that also start strictly inside this bucket (skewed inputs only)
-                const u32 cu = (u32)(((u64)u * E) / MSM_T), cu1 = (u32)(((u64)(u + 1) * E) / MSM_T);
+            ge part = psum[ch];
+            for (int u = (int)ch - 1; u >= 0; u--) {  // earlier chunks that also start strictly inside this bucket (skewed inputs only)
+                const u32 cu = (u32)(((u64)u * E) / ACC_T), cu1 = (u32)(((u64)(u + 1) * E) / ACC_T);
                 if (cu <= cursor[k_first - 1]) break;
                 if (cu1 > cu) ge_add_nc(part, part, psum[u]);
             }
@@ -505,7 +502,7 @@ static MsmScratch msm_scratch_layout(void* base, size_t n_msm, size_t n_terms, s
     m.bsum = reinterpret_cast<ge*>(static_cast<u8*>(base) + o);
     o += n_msm * K * sizeof(ge);
     m.psum = reinterpret_cast<ge*>(static_cast<u8*>(base) + o);
-    o += n_msm * MSM_T * sizeof(ge);
+    o += n_msm * ACC_T * sizeof(ge);
     m.tmp = reinterpret_cast<ge*>(static_cast<u8*>(base) + o);
     o += n_msm * out_items * sizeof(ge);
     m.bytes = o;
@@ -536,7 +533,7 @@ int32_t fold_generators_launch(bbp_ctx* ctx, uint32_t n_proofs, const sc* g_dev,
     }
     {
         ScopedEvent ev(ctx, TAG_MSM, stream);
-        hipLaunchKernelGGL(k_msm_acc<1>, dim3((u32)n_work), dim3(MSM_T), 0, stream, ctx->ptable, m.sorted, m.cursor, n_sub, m.bsum, m.psum,
+        hipLaunchKernelGGL(k_msm_acc<1>, dim3((u32)n_work), dim3(ACC_T), 0, stream, ctx->ptable, m.sorted, m.cursor, n_sub, m.bsum, m.psum,
                            split > 1 ? m.tmp : out_dev, (const u32*)nullptr, ctx->health);
         BBP_HIP_TRY(ctx, hipGetLastError());
     }
@@ -586,7 +583,7 @@ int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* sc
     }
     {
         ScopedEvent ev(ctx, TAG_MSM, stream);
-        hipLaunchKernelGGL(k_msm_acc<0>, dim3(n_work), dim3(MSM_T), 0, stream, ctx->ptable, m.sorted, m.cursor, n_sub, m.bsum, m.psum,
+        hipLaunchKernelGGL(k_msm_acc<0>, dim3(n_work), dim3(ACC_T), 0, stream, ctx->ptable, m.sorted, m.cursor, n_sub, m.bsum, m.psum,
                            split > 1 ? m.tmp : out_points_dev, n_active_dev, ctx->health);
         BBP_HIP_TRY(ctx, hipGetLastError());
     }
