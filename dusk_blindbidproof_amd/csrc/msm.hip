@@ -275,7 +275,11 @@ void k_msm_acc(const niels_row* __restrict__ ptable, const u32* __restrict__ sor
     const u32 E = cursor[K];  // may be 0 (an empty sub-MSM): then no chunk has entries and no bucket is non-empty, E never divides
     ge* bsum = bsum_all + msm * (size_t)K;               // [K] bucket k at index k-1
     ge* psum = psum_all + msm * (size_t)ACC_T;           // [ACC_T]
+#ifdef BBP_KO_ACC_PERMILLE  // timing experiment (wrong results): every lane walks only this share of its chunk
+    const u32 c0 = (u32)(((u64)tid * E) / ACC_T), c1 = c0 + (u32)(((u64)((u32)(((u64)(tid + 1) * E) / ACC_T) - c0) * BBP_KO_ACC_PERMILLE) / 1000);
+#else
     const u32 c0 = (u32)(((u64)tid * E) / ACC_T), c1 = (u32)(((u64)(tid + 1) * E) / ACC_T);
+#endif
 #ifdef BBP_MSM_PROF
     const unsigned long long clk0 = clock64();
 #endif
@@ -347,6 +351,11 @@ __global__ __launch_bounds__(MSM_T) void k_msm_fold(const u32* __restrict__ curs
     const u32 E = cursor[K];
     ge* bsum = bsum_all + msm * (size_t)K;
     const ge* psum = psum_all + msm * (size_t)ACC_T;
+#ifdef BBP_KO_FOLD  // timing experiment (wrong results): the fold does nothing but write some point per output
+    if (MODE == 0) { if (tid == 0) out[msm] = bsum[0]; }
+    else if (tid < FOLD_CLS) out[msm * FOLD_CLS + tid] = bsum[tid];
+    return;
+#endif
     // P. the chunk-leading partial sums of the accumulate kernel's ACC_T chunks go into their buckets.  A chunk that started
     //    strictly inside a bucket left that leading partial in psum[chunk]; when several consecutive chunks start inside the same
     //    (heavy) bucket, the LAST of them adds the whole run -- one writer per bucket.  Chunks are dealt to the MSM_T lanes.
@@ -457,6 +466,157 @@ __global__ __launch_bounds__(MSM_T) void k_msm_fold(const u32* __restrict__ curs
             out[msm * FOLD_CLS + (tid / LPC)] = accq;
         }
     }
+}
+
+// k_msm_fold<0> on HALF a wavefront per MSM (two MSMs per 64-lane workgroup), for launches with many MSMs.  The fold is integer-issue
+// work like the accumulation (general additions, 10 multiplications each), and what it costs the pipeline is wave-instructions:
+// 128 lanes per MSM spend 2 wavefronts x 38 dependent additions = 76 wave-additions per MSM, most of them in the cross-lane phases that
+// only exist because the buckets are spread over many lanes; 32 lanes with 32 buckets each spend (8 + 64 + 17) / 2 = 44.5.  The chain
+// per wavefront is 2.3 times longer, so small launches (latency-bound: single proofs, split MSMs) keep the wide kernel.
+constexpr int FOLD2_L = 32;                       // lanes per MSM
+constexpr int FOLD2_G = MSM_K / FOLD2_L;          // 32 consecutive buckets per lane
+constexpr int FOLD2_LOG_G = 5;
+static_assert(FOLD2_G == 32 && ACC_T % FOLD2_L == 0, "fold geometry");
+
+__device__ __forceinline__ ge ge_shfl_down32(const ge& p, int d) {  // within each 32-lane half of the wavefront
+    ge r;
+    const u32* w = reinterpret_cast<const u32*>(&p);
+    u32* o = reinterpret_cast<u32*>(&r);
+#pragma unroll
+    for (int i = 0; i < GE_WORDS; i++) o[i] = (u32)__shfl_down((int)w[i], d, 32);
+    return r;
+}
+
+__device__ __forceinline__ void park_put(u32* park, int tid, const ge& p) {
+    const u32* w = reinterpret_cast<const u32*>(&p);
+#pragma unroll
+    for (int i = 0; i < GE_WORDS; i++) park[i * 64 + tid] = w[i];
+}
+
+__device__ __forceinline__ ge park_get(const u32* park, int tid) {
+    ge p;
+    u32* w = reinterpret_cast<u32*>(&p);
+#pragma unroll
+    for (int i = 0; i < GE_WORDS; i++) w[i] = park[i * 64 + tid];
+    return p;
+}
+
+__device__ __forceinline__ ge ld_ge(const ge* p) {
+    ge r;
+    const uint4* s = reinterpret_cast<const uint4*>(p);
+    u32* o = reinterpret_cast<u32*>(&r);
+#pragma unroll
+    for (int i = 0; i < GE_WORDS / 4; i++) {
+        const uint4 v = s[i];
+        o[4 * i] = v.x, o[4 * i + 1] = v.y, o[4 * i + 2] = v.z, o[4 * i + 3] = v.w;
+    }
+    return r;
+}
+
+#ifndef BBP_FOLD_WAVES
+#define BBP_FOLD_WAVES 3
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BBP_FOLD_WAVES, BBP_FOLD_WAVES))) void k_msm_fold_half(const u32* __restrict__ cursor_all, ge* __restrict__ bsum_all, const ge* __restrict__ psum_all,
+                                                       ge* __restrict__ out, u32 n_work, const u32* __restrict__ n_active) {
+    constexpr int K = MSM_K, G = FOLD2_G;
+    __shared__ u32 cursor2[2][K + 1];
+    __shared__ u32 park[GE_WORDS * 64];  // one point per lane, word-major (conflict-free)
+    const int tid = threadIdx.x, half = tid >> 5, l = tid & 31;
+    const u32 n_tot = n_active ? min(*n_active, n_work) : n_work;
+    if (2u * blockIdx.x >= n_tot) return;
+    __builtin_amdgcn_s_setprio(2);
+    const size_t msm = 2 * (size_t)blockIdx.x + half;
+    const bool valid = msm < n_tot;  // an odd launch leaves the last upper half idle: it sees an all-empty cursor and adds identities
+    u32* cursor = cursor2[half];
+    {
+        const u32* cur_in = cursor_all + msm * (size_t)(K + 1);
+        for (int k = l; k <= K; k += FOLD2_L) cursor[k] = valid ? cur_in[k] : 0u;
+    }
+    __syncthreads();
+    const u32 E = cursor[K];
+    ge* bsum = bsum_all + (valid ? msm : 0) * (size_t)K;
+    const ge* psum = psum_all + (valid ? msm : 0) * (size_t)ACC_T;
+    // P. chunk-leading partial sums into their buckets (see k_msm_fold): ACC_T / 32 chunks per lane
+#pragma unroll 1
+    for (u32 ch = l; ch < (u32)ACC_T; ch += FOLD2_L) {
+        const u32 c0 = (u32)(((u64)ch * E) / ACC_T), c1 = (u32)(((u64)(ch + 1) * E) / ACC_T);
+        bool last_of_run = false;
+        u32 k_first = 1;
+        if (c0 < c1) {
+            u32 lo = 1, hi = K;
+            while (lo < hi) {
+                u32 mid = (lo + hi) >> 1;
+                if (cursor[mid] > c0) hi = mid; else lo = mid + 1;
+            }
+            k_first = lo;
+            const bool inside = cursor[lo - 1] < c0;
+            last_of_run = inside && !(c1 < E && c1 > cursor[k_first - 1] && c1 < cursor[k_first]);
+        }
+        if (last_of_run) {
+            ge part = ld_ge(&psum[ch]);
+            for (int u = (int)ch - 1; u >= 0; u--) {  // earlier chunks that also start strictly inside this bucket (skewed inputs only)
+                const u32 cu = (u32)(((u64)u * E) / ACC_T), cu1 = (u32)(((u64)(u + 1) * E) / ACC_T);
+                if (cu <= cursor[k_first - 1]) break;
+                if (cu1 > cu) {  // (same addition site as below: the head is added last)
+                    const ge more = ld_ge(&psum[u]);
+                    part = ge_add(part, more);
+                }
+            }
+            const ge head = ld_ge(&bsum[k_first - 1]);
+            bsum[k_first - 1] = ge_add(head, part);
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // D2. running-sum fold over this lane's 32 buckets (high to low).  Registers are the scarce thing here (this wavefront should fit
+    //     beside two accumulate waves: 160 VGPRs): `total` is only touched once per bucket, so it lives in an LDS slot between uses.
+    ge running = ge_identity();
+    park_put(park, tid, ge_identity());
+#pragma unroll 1
+    for (int r = G; r >= 1; r--) {
+        const u32 k = (u32)l * G + r;
+        if (cursor[k] != cursor[k - 1]) {
+            const ge cur = ld_ge(&bsum[k - 1]);
+            running = ge_add(running, cur);
+        }
+        const ge total = park_get(park, tid);
+        park_put(park, tid, ge_add(total, running));
+    }
+
+    // E. cross-lane fold inside the half: W = sum_t total_t + G * sum_{t>=1} suffix_t, suffix_t = sum_{u>=t} running_u; result = 2 W - S.
+    //    ONE loop with one inlined addition and one inlined doubling: steps 0-4 are the suffix scan of `running`; step 5 is
+    //    x = total + 32 * suffix (total leaves the LDS slot, the suffix -- lane 0's is S -- takes it); steps 6-10 the tree sum of x;
+    //    step 11 the result 2 x - S in lane 0.
+    ge v = running;
+#pragma unroll 1
+    for (int it = 0; it < 12; it++) {
+        ge q;
+        bool take;
+        int n_dbl = 0;
+        if (it == 5) {
+            q = v;
+            v = park_get(park, tid);
+            park_put(park, tid, q);
+            n_dbl = FOLD2_LOG_G;
+            take = l >= 1;
+        } else if (it == 11) {
+            q = ge_neg(park_get(park, tid));
+            take = true;
+        } else {
+            const int d = it < 5 ? (1 << it) : (16 >> (it - 6));
+            q = ge_shfl_down32(v, d);
+            take = it < 5 ? (l + d < 32) : (l < d);
+        }
+        if (it == 11) {
+            v = ge_dbl(v);
+        } else {
+#pragma unroll 1
+            for (int i = 0; i < n_dbl; i++) q = ge_dbl(q);
+        }
+        if (take) v = ge_add(v, q);
+    }
+    if (l == 0 && valid) out[msm] = v;
 }
 
 // sums the `split` partial results of every MSM: out[o] = sum_j tmp[((o / items) * split + j) * items + o % items]
@@ -588,7 +748,13 @@ int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* sc
         BBP_HIP_TRY(ctx, hipGetLastError());
     }
     ScopedEvent evf(ctx, TAG_MSM_FOLD, stream);
-    hipLaunchKernelGGL(k_msm_fold<0>, dim3(n_work), dim3(MSM_T), 0, stream, m.cursor, m.bsum, m.psum, split > 1 ? m.tmp : out_points_dev, n_active_dev);
+    // many MSMs: the fold on half a wavefront per MSM (fewer wave-instructions); few: the 128-lane fold (shorter chain).  BBP_FOLD_HALF_FROM
+    static const u32 half_from = [] { const char* e = getenv("BBP_FOLD_HALF_FROM"); return e ? (u32)atoi(e) : 512u; }();
+    if (n_work >= half_from)
+        hipLaunchKernelGGL(k_msm_fold_half, dim3((n_work + 1) / 2), dim3(64), 0, stream, m.cursor, m.bsum, m.psum, split > 1 ? m.tmp : out_points_dev,
+                           n_work, n_active_dev);
+    else
+        hipLaunchKernelGGL(k_msm_fold<0>, dim3(n_work), dim3(MSM_T), 0, stream, m.cursor, m.bsum, m.psum, split > 1 ? m.tmp : out_points_dev, n_active_dev);
     BBP_HIP_TRY(ctx, hipGetLastError());
     if (split > 1) {
         hipLaunchKernelGGL(k_msm_reduce, dim3((n_msm + 63) / 64), dim3(64), lds_token(ctx), stream, n_msm, split, 1u, m.tmp, out_points_dev);

@@ -940,7 +940,12 @@ __global__ __launch_bounds__(TAIL_BLK) void k_tail_lr(u32 B, u32 n, u32 prev_rou
             s = sc_mul(c, ld_sc(&misc[(size_t)p * MS_COUNT + MS_W]));  // Q = w B
             T = btab;
         }
+#ifndef BBP_KO_TAIL  // (timing experiment, wrong results, when defined)
         q = ge_scalarmul_pieces(s, T);
+#else
+        q = T[0];
+        q.X.v[0] += (i32)(s.v[0] & 1u);
+#endif
     }
     const u32* w = reinterpret_cast<const u32*>(&q);
     for (int k = 0; k < GE_WORDS; k++) stage[k * TAIL_BLK + tid] = w[k];
