@@ -75,19 +75,8 @@ __device__ __forceinline__ ge xch_get(const u32* xch) {
     return p;
 }
 
-// one 128-byte row (one cache line) as the three field elements of a cached point, y+x and y-x already swapped for a negative
-// digit (the swap is two load offsets, not twenty selects).  The index is clamped: a corrupted scratch entry must never turn
-// into an out-of-bounds gather (a GPU fault here takes the whole node down); one v_min_u32 per ~1400-instruction iteration.
-struct row_regs {
-    fe ypx, ymx, xy2d;
-};
-
-__device__ __forceinline__ fe load_fe40(const u8* p) {  // 10 limbs at a 16-byte aligned address
-    const uint4 a = *reinterpret_cast<const uint4*>(p), b = *reinterpret_cast<const uint4*>(p + 16);
-    const uint2 c = *reinterpret_cast<const uint2*>(p + 32);
-    return fe{{(i32)a.x, (i32)a.y, (i32)a.z, (i32)a.w, (i32)b.x, (i32)b.y, (i32)b.z, (i32)b.w, (i32)c.x, (i32)c.y}};
-}
-
+// The index of a gathered row is clamped: a corrupted scratch entry must never turn into an out-of-bounds gather (a GPU fault here
+// takes the whole node down); one v_min_u32 per ~1400-instruction iteration.  (row_regs / load_row_at / ge_madd_row: point.h)
 __device__ __forceinline__ row_regs load_row(const niels_row* __restrict__ tab, u32 entry, u32* __restrict__ fault) {
     u32 row = entry & 0x7fffffffu;
     if (row > (u32)(TAB_BASES * MSM_POS - 1)) {  // never seen on sound scratch: clamp (no fault) AND say so (bbp_check_health)
@@ -97,33 +86,7 @@ __device__ __forceinline__ row_regs load_row(const niels_row* __restrict__ tab, 
 #ifdef BBP_EXP_ROWMASK  // experiment (wrong results): alias all gathers onto a cache-resident slice of the table
     row &= BBP_EXP_ROWMASK;
 #endif
-    const u8* p = reinterpret_cast<const u8*>(tab + row);
-    const u32 swap = (entry >> 31) << 6;  // 64 for a negative digit
-    row_regs r;
-    r.ypx = load_fe40(p + swap);
-    r.ymx = load_fe40(p + (swap ^ 64u));
-    const uint2 x0 = *reinterpret_cast<const uint2*>(p + 40);
-    const uint4 x1 = *reinterpret_cast<const uint4*>(p + 48);
-    const uint2 x2 = *reinterpret_cast<const uint2*>(p + 104), x3 = *reinterpret_cast<const uint2*>(p + 112);
-    r.xy2d = fe{{(i32)x0.x, (i32)x0.y, (i32)x1.x, (i32)x1.y, (i32)x1.z, (i32)x1.w, (i32)x2.x, (i32)x2.y, (i32)x3.x, (i32)x3.y}};
-    return r;
-}
-
-// acc +/- row: mixed addition (7M); for a negative digit y+x / y-x arrive swapped and D - C / D + C swap roles
-__device__ __forceinline__ ge ge_madd_row(const ge& p, const row_regs& q, bool neg) {
-    fe a = fe_mul(fe_sub(p.Y, p.X), q.ymx);
-    fe b = fe_mul(fe_add(p.Y, p.X), q.ypx);
-    fe c = fe_mul(p.T, q.xy2d);
-    fe d = fe_add(p.Z, p.Z);
-    fe e = fe_sub(b, a), h = fe_add(b, a);
-    fe f0 = fe_sub(d, c), g0 = fe_add(d, c);
-    fe f = fe_select(f0, g0, neg), g = fe_select(g0, f0, neg);
-    ge r;
-    r.X = fe_mul(e, f);
-    r.Y = fe_mul(g, h);
-    r.Z = fe_mul(f, g);
-    r.T = fe_mul(e, h);
-    return r;
+    return load_row_at(tab + row, entry >> 31);
 }
 
 // The cold phases (bucket fold, cross-lane reduction) call ONE out-of-line copy of the point addition / doubling: inlining
@@ -246,16 +209,25 @@ __global__ __launch_bounds__(SORT_T) void k_msm_sort(const u32* __restrict__ sca
     for (int k = tid; k <= K; k += SORT_T) cur_out[k] = k ? cursor[k] : 0u;  // cursor[k] = end offset of bucket k
 }
 
+// Workgroups of the accumulate kernel: ACC_WG lanes each, ACC_T / ACC_WG of them per MSM (chunk = global lane index within the MSM).
+// Measured: one wavefront per workgroup (64) lets the dispatcher place accumulate waves SIMD by SIMD and shortens the accumulate
+// launches by 7 %, but the thin kernels beside them lose as much and more (52.9 vs 51.6 ms per batch): the machine is saturated, a
+// kernel only gains what another loses.  One workgroup per MSM stays.
+#ifndef BBP_ACC_WG
+#define BBP_ACC_WG 256
+#endif
+constexpr int ACC_WG = BBP_ACC_WG, ACC_WGS = ACC_T / ACC_WG;
+static_assert(ACC_T % ACC_WG == 0 && ACC_WG % 64 == 0, "accumulate workgroup geometry");
+
 template <int MODE>
-__global__ __launch_bounds__(ACC_T) __attribute__((amdgpu_waves_per_eu(BBP_MSM_WAVES, BBP_MSM_WAVES_MAX)))
+__global__ __launch_bounds__(ACC_WG) __attribute__((amdgpu_waves_per_eu(BBP_MSM_WAVES, BBP_MSM_WAVES_MAX)))
 void k_msm_acc(const niels_row* __restrict__ ptable, const u32* __restrict__ sorted_all, const u32* __restrict__ cursor_all, u32 n /* sorted stride */,
                ge* __restrict__ bsum_all, ge* __restrict__ psum_all, ge* __restrict__ out, const u32* __restrict__ n_active, u32* __restrict__ fault) {
     constexpr int K = msm_geom<MODE>::K, W = msm_geom<MODE>::W, G = K / MSM_T;  // (G: unused here since the fold moved out)
     __shared__ u32 cursor[K + 1];
-    __shared__ u32 xch[GE_WORDS];
-    const int tid = threadIdx.x;
-    if (n_active && blockIdx.x >= *n_active) return;  // device-sized launch (see k_msm_sort)
-    const size_t msm = blockIdx.x;
+    const size_t msm = blockIdx.x / ACC_WGS;
+    const int tid = (int)(blockIdx.x % ACC_WGS) * ACC_WG + (int)threadIdx.x;  // chunk index within the MSM
+    if (n_active && msm >= *n_active) return;  // device-sized launch (see k_msm_sort)
     const u32* sorted = sorted_all + msm * (size_t)n * W;
 #ifdef BBP_MSM_PRIO
     __builtin_amdgcn_s_setprio(BBP_MSM_PRIO);
@@ -263,7 +235,7 @@ void k_msm_acc(const niels_row* __restrict__ ptable, const u32* __restrict__ sor
     MSM_PROF_BEGIN();
     {
         const u32* cur_in = cursor_all + msm * (size_t)(K + 1);
-        for (int k = tid; k <= K; k += ACC_T) cursor[k] = cur_in[k];
+        for (int k = threadIdx.x; k <= K; k += ACC_WG) cursor[k] = cur_in[k];
     }
     __syncthreads();
     MSM_PROF_MARK(1);
@@ -693,7 +665,7 @@ int32_t fold_generators_launch(bbp_ctx* ctx, uint32_t n_proofs, const sc* g_dev,
     }
     {
         ScopedEvent ev(ctx, TAG_MSM, stream);
-        hipLaunchKernelGGL(k_msm_acc<1>, dim3((u32)n_work), dim3(ACC_T), 0, stream, ctx->ptable, m.sorted, m.cursor, n_sub, m.bsum, m.psum,
+        hipLaunchKernelGGL(k_msm_acc<1>, dim3((u32)n_work * ACC_WGS), dim3(ACC_WG), 0, stream, ctx->ptable, m.sorted, m.cursor, n_sub, m.bsum, m.psum,
                            split > 1 ? m.tmp : out_dev, (const u32*)nullptr, ctx->health);
         BBP_HIP_TRY(ctx, hipGetLastError());
     }
@@ -743,7 +715,7 @@ int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* sc
     }
     {
         ScopedEvent ev(ctx, TAG_MSM, stream);
-        hipLaunchKernelGGL(k_msm_acc<0>, dim3(n_work), dim3(ACC_T), 0, stream, ctx->ptable, m.sorted, m.cursor, n_sub, m.bsum, m.psum,
+        hipLaunchKernelGGL(k_msm_acc<0>, dim3(n_work * ACC_WGS), dim3(ACC_WG), 0, stream, ctx->ptable, m.sorted, m.cursor, n_sub, m.bsum, m.psum,
                            split > 1 ? m.tmp : out_points_dev, n_active_dev, ctx->health);
         BBP_HIP_TRY(ctx, hipGetLastError());
     }

@@ -146,6 +146,51 @@ BBP_HD ge ge_dbl(const ge& p) {
     return r;
 }
 
+#if defined(__HIPCC__)
+// ---- 128-byte limb rows in registers (device only): the MSM row table (msm.hip) and the per-proof tail tables (prover.hip) --------
+// one row as the three field elements of a cached point, y+x and y-x already swapped for a negative digit (the swap is two load
+// offsets, not twenty selects)
+struct row_regs {
+    fe ypx, ymx, xy2d;
+};
+
+__device__ __forceinline__ fe load_fe40(const u8* p) {  // 10 limbs at a 16-byte aligned address
+    const uint4 a = *reinterpret_cast<const uint4*>(p), b = *reinterpret_cast<const uint4*>(p + 16);
+    const uint2 c = *reinterpret_cast<const uint2*>(p + 32);
+    return fe{{(i32)a.x, (i32)a.y, (i32)a.z, (i32)a.w, (i32)b.x, (i32)b.y, (i32)b.z, (i32)b.w, (i32)c.x, (i32)c.y}};
+}
+
+__device__ __forceinline__ row_regs load_row_at(const niels_row* __restrict__ row, u32 neg) {  // neg: 0 or 1
+    const u8* p = reinterpret_cast<const u8*>(row);
+    const u32 swap = neg << 6;  // 64 for a negative digit
+    row_regs r;
+    r.ypx = load_fe40(p + swap);
+    r.ymx = load_fe40(p + (swap ^ 64u));
+    const uint2 x0 = *reinterpret_cast<const uint2*>(p + 40);
+    const uint4 x1 = *reinterpret_cast<const uint4*>(p + 48);
+    const uint2 x2 = *reinterpret_cast<const uint2*>(p + 104), x3 = *reinterpret_cast<const uint2*>(p + 112);
+    r.xy2d = fe{{(i32)x0.x, (i32)x0.y, (i32)x1.x, (i32)x1.y, (i32)x1.z, (i32)x1.w, (i32)x2.x, (i32)x2.y, (i32)x3.x, (i32)x3.y}};
+    return r;
+}
+
+// acc +/- row: mixed addition (7M); for a negative digit y+x / y-x arrive swapped and D - C / D + C swap roles
+__device__ __forceinline__ ge ge_madd_row(const ge& p, const row_regs& q, bool neg) {
+    fe a = fe_mul(fe_sub(p.Y, p.X), q.ymx);
+    fe b = fe_mul(fe_add(p.Y, p.X), q.ypx);
+    fe c = fe_mul(p.T, q.xy2d);
+    fe d = fe_add(p.Z, p.Z);
+    fe e = fe_sub(b, a), h = fe_add(b, a);
+    fe f0 = fe_sub(d, c), g0 = fe_add(d, c);
+    fe f = fe_select(f0, g0, neg), g = fe_select(g0, f0, neg);
+    ge r;
+    r.X = fe_mul(e, f);
+    r.Y = fe_mul(g, h);
+    r.Z = fe_mul(f, g);
+    r.T = fe_mul(e, h);
+    return r;
+}
+#endif
+
 // affine cached form given 1/Z
 BBP_HD ge_niels ge_to_niels(const ge& p, const fe& zinv) {
     fe x = fe_mul(p.X, zinv), y = fe_mul(p.Y, zinv);

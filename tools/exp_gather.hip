@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "point.h"
 
@@ -78,6 +79,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     sink[t] = (u32)(acc.X.v[0] ^ acc.T.v[3] ^ acc.Y.v[5] ^ acc.Z.v[7]);
 }
 
+
 #define CK(x)                                                                      \
     do {                                                                           \
         hipError_t e_ = (x);                                                       \
@@ -87,7 +89,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }                                                                          \
     } while (0)
 
+// second mode: `exp_gather cumask` -- the same loop (64 MB table) on streams restricted to 64 / 128 / 192 / 256 CUs: does the rate grow with the
+// CU count (issue-bound) or stay put (power / clock bound)?
+static int cumask_mode() {
+    const size_t bytes = 64u << 20;
+    const u32 n_rows = (u32)(bytes / 128);
+    u8* tab = nullptr;
+    u32* sink = nullptr;
+    const int wgs = 8192;
+    CK(hipMalloc(&tab, bytes));
+    CK(hipMalloc(&sink, (size_t)wgs * 256 * 4));
+    CK(hipMemset(tab, 1, bytes));
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    for (int rep = 0; rep < 2; rep++)
+        for (int cus : {32, 64, 128, 192, 224, 256}) {
+            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            // CU i of the mask: spread over the 8 XCDs round-robin the way the runtime numbers them (bit i = CU i)
+            for (int i = 0; i < cus; i++) {
+                const int cu = (i % 8) * 32 + i / 8;  // XCD-major numbering assumed: take CUs evenly from every XCD
+                mask[cu / 32] |= 1u << (cu % 32);
+            }
+            hipStream_t st;
+            CK(hipExtStreamCreateWithCUMask(&st, 8, mask));
+            hipLaunchKernelGGL(k_gather, dim3(wgs), dim3(256), 0, st, tab, n_rows, 40u, sink);  // warm
+            CK(hipEventRecord(a, st));
+            hipLaunchKernelGGL(k_gather, dim3(wgs), dim3(256), 0, st, tab, n_rows, 400u, sink);
+            CK(hipEventRecord(b, st));
+            CK(hipEventSynchronize(b));
+            float ms = 0;
+            CK(hipEventElapsedTime(&ms, a, b));
+            const double adds = (double)wgs * 256.0 * 400;
+            printf("CUs %3d: %.2f ms  %.3e additions/s  %.3e per CU\n", cus, ms, adds / (ms * 1e-3), adds / (ms * 1e-3) / cus);
+            fflush(stdout);
+            CK(hipStreamDestroy(st));
+        }
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "cumask")) return cumask_mode();
     const double gib = argc > 1 ? atof(argv[1]) : 0.25;
     const int wgs = argc > 2 ? atoi(argv[2]) : 4096;
     const u32 iters = argc > 3 ? (u32)atoi(argv[3]) : 152u;
