@@ -721,8 +721,7 @@ int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* sc
     }
     ScopedEvent evf(ctx, TAG_MSM_FOLD, stream);
     // many MSMs: the fold on half a wavefront per MSM (fewer wave-instructions); few: the 128-lane fold (shorter chain).  BBP_FOLD_HALF_FROM
-    static const u32 half_from = [] { const char* e = getenv("BBP_FOLD_HALF_FROM"); return e ? (u32)atoi(e) : 512u; }();
-    if (n_work >= half_from)
+    if (n_work >= (u32)ctx->fold_half_from)
         hipLaunchKernelGGL(k_msm_fold_half, dim3((n_work + 1) / 2), dim3(64), 0, stream, m.cursor, m.bsum, m.psum, split > 1 ? m.tmp : out_points_dev,
                            n_work, n_active_dev);
     else

@@ -69,6 +69,48 @@ def test_msm_fuzz(ctx, bbp, oc, seed):
         assert got == exp, (seed, case, layout, n_terms, B)
 
 
+def test_msm_fuzz_half_wavefront_fold(bbp, oc):
+    """k_msm_fold_half (two MSMs per wavefront, 32 lanes x 32 buckets) serves launches of 512 MSMs and more by default; with
+    BBP_FOLD_HALF_FROM=1 every launch uses it: odd MSM counts (idle upper half), split MSMs, one-term and empty MSMs, every term in one
+    bucket (runs of chunk-leading partial sums), and the full-width 4097-term shape -- all against the C oracle."""
+    import os
+    old = os.environ.get("BBP_FOLD_HALF_FROM")
+    os.environ["BBP_FOLD_HALF_FROM"] = "1"
+    try:
+        c2 = bbp.Context(0)
+    finally:
+        if old is None:
+            os.environ.pop("BBP_FOLD_HALF_FROM", None)
+        else:
+            os.environ["BBP_FOLD_HALF_FROM"] = old
+    try:
+        rnd = random.Random(77)
+        shapes = [(bbp.LAYOUT_BLIND_G_H, 1, 1), (bbp.LAYOUT_BLIND_G_H, 3, 3), (bbp.LAYOUT_BLIND_G, 34, 5), (bbp.LAYOUT_BLIND_G_H, 129, 127),
+                  (bbp.LAYOUT_BLIND_G_H, 257, 200), (bbp.LAYOUT_BLIND_G, 1467, 9), (bbp.LAYOUT_BLIND_G_H, 2933, 3), (bbp.LAYOUT_BLIND_G_H, 4097, 2),
+                  (bbp.LAYOUT_BLIND_G_H, 2049, 65)]
+        for layout, n_terms, B in shapes:
+            repeated = _pattern_scalar(rnd)
+            rows = []
+            for b in range(B):
+                style = (b + n_terms) % 4
+                if style == 0:
+                    row = [_pattern_scalar(rnd) for _ in range(n_terms)]
+                elif style == 1:
+                    row = [repeated] * n_terms
+                elif style == 2:
+                    row = [0] * n_terms
+                    row[rnd.randrange(n_terms)] = _pattern_scalar(rnd)
+                else:
+                    row = [rnd.randrange(L) for _ in range(n_terms)]
+                rows.append(b"".join(rs.sc_bytes(v) for v in row))
+            got = c2.msm_batch(B, n_terms, b"".join(rows), layout)
+            exp = oc.msm_layout_many(rows, [n_terms] * B, [layout] * B, threads=8)
+            assert got == exp, (layout, n_terms, B)
+        assert c2.health() == 0
+    finally:
+        c2.close()
+
+
 @pytest.mark.parametrize("seed", [11, 12])
 def test_prove_verify_fuzz(ctx, bbp, oc, seed):
     rnd = random.Random(seed)

@@ -384,6 +384,8 @@ def test_calls_from_different_streams_are_serialised(ctx, oc, bbp):
     {"BBP_RNG_COOP": "0"},                                      # TranscriptRng draw chain on one lane per proof (round-1 path)
     {"BBP_RNG_COOP": "1", "BBP_RNG_BLOCK": "64", "BBP_SERIAL_LDS": "0"},  # cooperative rng forced: one wavefront (two proofs) per workgroup, not fenced
     {"BBP_RNG_COOP": "1", "BBP_RNG_BLOCK": "1024"},             # cooperative rng forced: 32 proofs per reserved CU
+    {"BBP_FOLD_HALF_FROM": "1"},                                # every MSM launch folds on half a wavefront per MSM
+    {"BBP_FOLD_HALF_FROM": "1000000"},                          # ... and none does (128 lanes per MSM)
 ])
 def test_engine_schedules_give_identical_bytes(bbp, oc, knobs):
     """The scheduling knobs (slices, tail round, serial-kernel fencing, stagger) change WHEN and HOW work runs, never the bytes:
