@@ -209,6 +209,135 @@ __global__ __launch_bounds__(SORT_T) void k_msm_sort(const u32* __restrict__ sca
     for (int k = tid; k <= K; k += SORT_T) cur_out[k] = k ? cursor[k] : 0u;  // cursor[k] = end offset of bucket k
 }
 
+// k_msm_sort with the counting-sort scatter STAGED THROUGH LDS.  The plain kernel's scatter is 72 % of its time: every entry is a 4-byte
+// store to its own cache line, bound by L2 write requests (~2 * 10^11 /s).  Here the buckets are walked in windows of at most SORT_CAP
+// entries (consecutive buckets; the window boundaries come from the prefix sums, so every lane finds the same ones): a pass re-walks the
+// lane's NAF digits (cheap), places the entries of the window's buckets in an LDS image with the same LDS atomics as before, and the
+// workgroup then writes the image out as full cache lines.  A bucket larger than the image (adversarial scalars only) takes a pass of
+// its own with direct stores.  Entry order inside a bucket differs from the plain kernel's; sums do not care.
+template <int MODE> struct sort_cap { static constexpr u32 V = 16384; };
+template <> struct sort_cap<1> { static constexpr u32 V = 8192; };
+
+template <int MODE>
+__global__ __launch_bounds__(SORT_T) void k_msm_sort_staged(const u32* __restrict__ scal_a, const u32* __restrict__ aux, u32 n_total, u32 n_idx_sets,
+                                                             u32 n_sub, u32 split, u32* __restrict__ sorted_all, u32* __restrict__ cursor_all,
+                                                             const u32* __restrict__ msm_map, const u32* __restrict__ n_active) {
+    constexpr int K = msm_geom<MODE>::K, NAF = msm_geom<MODE>::NAF, W = msm_geom<MODE>::W, G = K / SORT_T;
+    constexpr u32 CAP = sort_cap<MODE>::V;
+    __shared__ u32 start[K + 2];  // start[k] = position of bucket k's first entry (k = 1..K), start[K + 1] = number of entries
+    __shared__ u32 fill[K + 1];   // histogram, then entries placed so far per bucket
+    __shared__ u32 part[SORT_T];
+    __shared__ u32 stage[CAP];
+    const int tid = threadIdx.x;
+    if (n_active && blockIdx.x >= *n_active) return;
+    const size_t work = blockIdx.x, msm = work / split;
+    const u32 i0 = (u32)(work % split) * n_sub;
+    const u32 n = i0 < n_total ? min(n_sub, n_total - i0) : 0u;
+    __builtin_amdgcn_s_setprio(3);
+    const u32* sbase;
+    const u32* base_idx = nullptr;
+    u32 base0 = 0;
+    if (MODE == 0) {
+        const size_t src = msm_map ? (size_t)msm_map[msm] : msm;
+        sbase = scal_a + (src * (size_t)n_total + i0) * 8;
+        base_idx = aux + (size_t)(msm % n_idx_sets) * n_total + i0;
+    } else {
+        const u32 side = (u32)msm & 1u;
+        sbase = (side ? aux : scal_a) + ((msm >> 1) * (size_t)2048 + i0) * 8;
+        base0 = (side ? BBP_BASE_H0 : BBP_BASE_G0) + i0;
+    }
+    u32* sorted = sorted_all + work * (size_t)n_sub * W;
+    auto key = [&](u32 i, u32 mag) -> u32 { return (MODE == 0 ? 0u : ((i0 + i) & (FOLD_CLS - 1)) * FOLD_M) + ((mag + 1) >> 1); };
+
+    for (int k = tid; k <= K; k += SORT_T) fill[k] = 0;
+    __syncthreads();
+    // A. histogram
+    for (u32 i = tid; i < n; i += SORT_T) {
+        const uint4* sp = reinterpret_cast<const uint4*>(sbase + (size_t)i * 8);
+        uint4 lo = sp[0], hi = sp[1];
+        const u32 s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        if (MODE == 0 && base_idx[i] == MSM_SKIP_BASE) continue;
+        sc_for_each_naf_digit<NAF>(s, [&](u32, u32 mag, u32) { atomicAdd(&fill[key(i, mag)], 1u); });
+    }
+    __syncthreads();
+    // B. bucket start offsets (block-wide exclusive scan as in k_msm_sort), counters back to zero
+    {
+        u32 local = 0;
+        for (int r = 1; r <= G; r++) local += fill[tid * G + r];
+        const int lane = tid & 63, wave = tid >> 6;
+        u32 incl = local;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const u32 up = (u32)__shfl_up((int)incl, d, 64);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) part[wave] = incl;
+        __syncthreads();
+        if (tid < 64) {
+            constexpr int NW = SORT_T / 64;
+            u32 v = tid < NW ? part[tid] : 0u, sc_ = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const u32 up = (u32)__shfl_up((int)sc_, d, 64);
+                if (tid >= d) sc_ += up;
+            }
+            if (tid < NW) part[tid] = sc_ - v;
+        }
+        __syncthreads();
+        u32 base = part[wave] + incl - local;
+        for (int r = 1; r <= G; r++) {
+            const u32 c = fill[tid * G + r];
+            start[tid * G + r] = base;
+            fill[tid * G + r] = 0;
+            base += c;
+        }
+        if (tid == SORT_T - 1) start[K + 1] = base;
+        if (tid == 0) start[0] = 0;
+    }
+    __syncthreads();
+    // C. scatter, window by window
+    u32 kb = 1;
+    while (kb <= (u32)K) {
+        const u32 base = start[kb];
+        const bool direct = start[kb + 1] - base > CAP;  // one bucket larger than the image
+        u32 ke = kb + 1;
+        if (!direct) {  // largest ke in [kb + 1, K + 1] with start[ke] - base <= CAP
+            u32 lo = kb + 1, hi = (u32)K + 1;
+            while (lo < hi) {
+                const u32 mid = (lo + hi + 1) >> 1;
+                if (start[mid] - base <= CAP) lo = mid; else hi = mid - 1;
+            }
+            ke = lo;
+        }
+        if (start[ke] != base) {  // (windows of empty buckets have nothing to place)
+            for (u32 i = tid; i < n; i += SORT_T) {
+                const uint4* sp = reinterpret_cast<const uint4*>(sbase + (size_t)i * 8);
+                uint4 lo4 = sp[0], hi4 = sp[1];
+                const u32 s[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+                if (MODE == 0 && base_idx[i] == MSM_SKIP_BASE) continue;
+                const u32 tb = (MODE == 0 ? base_idx[i] : base0 + i) * MSM_POS;
+                sc_for_each_naf_digit<NAF>(s, [&](u32 pos, u32 mag, u32 neg) {
+                    const u32 k = key(i, mag);
+                    if (k >= kb && k < ke) {
+                        const u32 at = start[k] + atomicAdd(&fill[k], 1u);
+                        const u32 ent = (tb + pos) | (neg << 31);
+                        if (direct) sorted[at] = ent; else stage[at - base] = ent;
+                    }
+                });
+            }
+            __syncthreads();
+            if (!direct) {
+                const u32 cnt = start[ke] - base;
+                for (u32 i = tid; i < cnt; i += SORT_T) sorted[base + i] = stage[i];
+            }
+            __syncthreads();
+        }
+        kb = ke;
+    }
+    u32* cur_out = cursor_all + work * (size_t)(K + 1);
+    for (int k = tid; k <= K; k += SORT_T) cur_out[k] = k ? start[k + 1] : 0u;  // end offset of bucket k
+}
+
 // Workgroups of the accumulate kernel: ACC_WG lanes each, ACC_T / ACC_WG of them per MSM (chunk = global lane index within the MSM).
 // Measured: one wavefront per workgroup (64) lets the dispatcher place accumulate waves SIMD by SIMD and shortens the accumulate
 // launches by 7 %, but the thin kernels beside them lose as much and more (52.9 vs 51.6 ms per batch): the machine is saturated, a
@@ -486,7 +615,7 @@ __device__ __forceinline__ ge ld_ge(const ge* p) {
 }
 
 #ifndef BBP_FOLD_WAVES
-#define BBP_FOLD_WAVES 3
+#define BBP_FOLD_WAVES 2
 #endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BBP_FOLD_WAVES, BBP_FOLD_WAVES))) void k_msm_fold_half(const u32* __restrict__ cursor_all, ge* __restrict__ bsum_all, const ge* __restrict__ psum_all,
                                                        ge* __restrict__ out, u32 n_work, const u32* __restrict__ n_active) {
@@ -659,8 +788,12 @@ int32_t fold_generators_launch(bbp_ctx* ctx, uint32_t n_proofs, const sc* g_dev,
     const MsmScratch m = msm_scratch_layout(scratch.p, n_work, n_sub, FOLD_W, FOLD_K, FOLD_CLS);
     {
         ScopedEvent ev(ctx, TAG_MSM_SORT, stream);
-        hipLaunchKernelGGL(k_msm_sort<1>, dim3((u32)n_work), dim3(SORT_T), 0, stream, (const u32*)g_dev, (const u32*)h_dev, 2048u, 1u, n_sub, split,
-                           m.sorted, m.cursor, (const u32*)nullptr, (const u32*)nullptr);
+        if (ctx->sort_staged & 2)
+            hipLaunchKernelGGL(k_msm_sort_staged<1>, dim3((u32)n_work), dim3(SORT_T), 0, stream, (const u32*)g_dev, (const u32*)h_dev, 2048u, 1u, n_sub, split,
+                               m.sorted, m.cursor, (const u32*)nullptr, (const u32*)nullptr);
+        else
+            hipLaunchKernelGGL(k_msm_sort<1>, dim3((u32)n_work), dim3(SORT_T), 0, stream, (const u32*)g_dev, (const u32*)h_dev, 2048u, 1u, n_sub, split,
+                               m.sorted, m.cursor, (const u32*)nullptr, (const u32*)nullptr);
         BBP_HIP_TRY(ctx, hipGetLastError());
     }
     {
@@ -709,8 +842,12 @@ int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* sc
     const MsmScratch m = msm_scratch_layout(scratch.p, n_work, n_sub, MSM_W, MSM_K);
     {
         ScopedEvent ev(ctx, TAG_MSM_SORT, stream);
-        hipLaunchKernelGGL(k_msm_sort<0>, dim3(n_work), dim3(SORT_T), 0, stream, scalars_dev, base_idx_dev, n_terms, n_idx_sets, n_sub, split,
-                           m.sorted, m.cursor, msm_map_dev, n_active_dev);
+        if (ctx->sort_staged & 1)
+            hipLaunchKernelGGL(k_msm_sort_staged<0>, dim3(n_work), dim3(SORT_T), 0, stream, scalars_dev, base_idx_dev, n_terms, n_idx_sets, n_sub, split,
+                               m.sorted, m.cursor, msm_map_dev, n_active_dev);
+        else
+            hipLaunchKernelGGL(k_msm_sort<0>, dim3(n_work), dim3(SORT_T), 0, stream, scalars_dev, base_idx_dev, n_terms, n_idx_sets, n_sub, split,
+                               m.sorted, m.cursor, msm_map_dev, n_active_dev);
         BBP_HIP_TRY(ctx, hipGetLastError());
     }
     {
