@@ -179,7 +179,7 @@ static int32_t init_body(int32_t device, bbp_ctx** out) {
     }
     if (const char* e = getenv("BBP_SERIAL_BLOCK")) ctx->serial_block = atoi(e) == 64 ? 64 : atoi(e) == 128 ? 128 : 256;
     if (const char* e = getenv("BBP_SERIAL_LDS")) ctx->serial_lds = atoi(e) < 0 ? 0 : atoi(e) > 160 * 1024 ? 160 * 1024 : atoi(e);
-    if (const char* e = getenv("BBP_SORT_STAGED")) ctx->sort_staged = atoi(e) & 3;
+    if (const char* e = getenv("BBP_SORT_STAGED")) ctx->sort_staged = atoi(e) & 7;
     if (const char* e = getenv("BBP_FOLD_HALF_FROM")) ctx->fold_half_from = atoi(e) < 1 ? 1 : atoi(e);
     if (const char* e = getenv("BBP_SLICES")) ctx->slices = atoi(e) < 1 ? 1 : atoi(e) > bbp_ctx::MAX_SLICES ? bbp_ctx::MAX_SLICES : atoi(e);
     for (int i = 0; i < bbp_ctx::PROVE_BUFS; i++) {
