@@ -784,10 +784,17 @@ __device__ ge ge_double_scalarmul(const sc& s1, const ge& P1, const sc& s2, cons
     return acc;
 }
 
-// Tail tables: for a point P the multiples m * 2^(64 k) * P, m = 1..8, k = 0..3 (32 extended points).  A scalar multiplication
-// over such a table is 60 doublings + 64 additions (signed radix-16 digits, four 64-bit pieces sharing the doublings) instead of
-// 252 + 64 + 7, and the tables of the 64 materialised generators are built once and used by all five tail rounds.
-constexpr int TAIL_TAB = 32;
+// Tail tables: for a point P the multiples m * 2^(w k) * P, m = 1..8, k = 0..TAIL_PIECES-1, w = 256 / TAIL_PIECES.  A scalar
+// multiplication over such a table is (w - 4) doublings + 64 additions (signed radix-16 digits, the pieces share the doublings)
+// instead of 252 + 64 + 7, and the tables of the 64 materialised generators are built once and used by all five tail rounds.
+// Four 64-bit pieces: 60 doublings per multiplication, 192 to build a table; eight 32-bit pieces: 28 and 224 (+ 28 additions): the
+// tail launches are chain-bound, a table serves five rounds.
+#ifndef BBP_TAIL_PIECES
+#define BBP_TAIL_PIECES 8
+#endif
+constexpr int TAIL_PIECES = BBP_TAIL_PIECES, TAIL_PIECE_BITS = 256 / TAIL_PIECES, TAIL_DIGITS = TAIL_PIECE_BITS / 4;
+constexpr int TAIL_TAB = 8 * TAIL_PIECES;
+static_assert(TAIL_PIECES == 4 || TAIL_PIECES == 8 || TAIL_PIECES == 16, "tail table geometry");
 // (64-lane workgroups and a 2-3 waves/SIMD register budget: with the default 128-VGPR cap this kernel spilled 216 registers)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 3))) void k_tail_tables(u32 count, const ge* __restrict__ pts, ge* __restrict__ tab) {
     BBP_THIN_PRIO();
@@ -795,15 +802,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 3))) void
     if (t >= count) return;
     ge P = pts[t];
     ge* T = tab + (size_t)t * TAIL_TAB;
-    for (int k = 0; k < 4; k++) {
+#pragma unroll 1
+    for (int k = 0; k < TAIL_PIECES; k++) {
         ge cur = P;
         T[8 * k] = P;
+#pragma unroll 1
         for (int i = 1; i < 8; i++) {
             cur = ge_add(cur, P);
             T[8 * k + i] = cur;
         }
-        if (k < 3)
-            for (int i = 0; i < 64; i++) P = ge_dbl(P);
+        if (k < TAIL_PIECES - 1) {
+#pragma unroll 1
+            for (int i = 0; i < TAIL_PIECE_BITS; i++) P = ge_dbl(P);
+        }
     }
 }
 
@@ -817,15 +828,15 @@ __device__ ge ge_scalarmul_pieces(const sc& s, const ge* __restrict__ T) {
         if (j < 63) cm |= (u64)c << (j + 1);
     }
     ge acc = ge_identity();
-    for (int r = 15; r >= 0; r--) {
-        if (r != 15) {
+    for (int r = TAIL_DIGITS - 1; r >= 0; r--) {
+        if (r != TAIL_DIGITS - 1) {
             acc = ge_dbl(acc);
             acc = ge_dbl(acc);
             acc = ge_dbl(acc);
             acc = ge_dbl(acc);
         }
-        for (int k = 0; k < 4; k++) {
-            const int j = 16 * k + r;
+        for (int k = 0; k < TAIL_PIECES; k++) {
+            const int j = TAIL_DIGITS * k + r;
             const int d = (int)((s.v[j >> 3] >> (4 * (j & 7))) & 15u) + (int)((cm >> j) & 1u) - 16 * (int)((j < 63) ? ((cm >> (j + 1)) & 1u) : 0u);
             if (d != 0) {
                 ge q = T[8 * k + (d > 0 ? d : -d) - 1];
