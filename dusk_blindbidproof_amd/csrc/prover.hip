@@ -818,7 +818,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 3))) void
     }
 }
 
-__device__ ge ge_scalarmul_pieces(const sc& s, const ge* __restrict__ T) {
+// pieces k_lo <= k < k_hi only: the partial product sum_k 2^(w k) * (piece k of s) * P
+__device__ ge ge_scalarmul_pieces(const sc& s, const ge* __restrict__ T, int k_lo = 0, int k_hi = TAIL_PIECES) {
     // carry mask of the signed radix-16 recoding: bit j = carry INTO digit j (a canonical scalar never carries out of digit 63)
     u64 cm = 0;
     u32 c = 0;
@@ -835,7 +836,7 @@ __device__ ge ge_scalarmul_pieces(const sc& s, const ge* __restrict__ T) {
             acc = ge_dbl(acc);
             acc = ge_dbl(acc);
         }
-        for (int k = 0; k < TAIL_PIECES; k++) {
+        for (int k = k_lo; k < k_hi; k++) {
             const int j = TAIL_DIGITS * k + r;
             const int d = (int)((s.v[j >> 3] >> (4 * (j & 7))) & 15u) + (int)((cm >> j) & 1u) - 16 * (int)((j < 63) ? ((cm >> (j + 1)) & 1u) : 0u);
             if (d != 0) {
@@ -866,11 +867,17 @@ __global__ void k_tail_init(u32 B, sc* __restrict__ g_all, sc* __restrict__ h_al
 // With `prev_round` != 0 the block first finishes the previous round: the first lane of each proof absorbs L, R of that round,
 // draws u and inverts it (the other lanes wait), then the proof's lanes fold a, b to length 2n and update gg, hh in parallel.
 // Three proofs share a 256-lane block (66 lanes each: 33 terms a side), 77 % of the lanes doing scalar multiplications instead of
-// the 52 % of one proof per 128 lanes.
-#ifndef BBP_TAIL_BLK
-#define BBP_TAIL_BLK 256
+// the 52 % of one proof per 128 lanes.  A term can be SPLIT over TAIL_SPLIT lanes, each taking a share of the table's pieces (a shorter
+// chain per lane, the doublings paid once per share): with two shares measured 52.2 instead of 50.2 ms per batch -- the tail is bound
+// by its work like everything else, not by its chain -- so one lane per term stays.
+#ifndef BBP_TAIL_SPLIT
+#define BBP_TAIL_SPLIT 1
 #endif
-constexpr int TAIL_BLK = BBP_TAIL_BLK, TAIL_LP = 66, TAIL_PPB = TAIL_BLK / TAIL_LP;
+#ifndef BBP_TAIL_BLK
+#define BBP_TAIL_BLK (BBP_TAIL_SPLIT == 1 ? 256 : 320)
+#endif
+constexpr int TAIL_SPLIT = BBP_TAIL_SPLIT, TAIL_LS = 33 * TAIL_SPLIT, TAIL_BLK = BBP_TAIL_BLK, TAIL_LP = 2 * TAIL_LS, TAIL_PPB = TAIL_BLK / TAIL_LP;
+static_assert(TAIL_PIECES % TAIL_SPLIT == 0 && TAIL_PPB >= 1, "tail kernel geometry");
 __global__ __launch_bounds__(TAIL_BLK) void k_tail_lr(u32 B, u32 n, u32 prev_round, u32 m, const u32* __restrict__ enc, merlin_transcript* __restrict__ tr,
                                                        const sc* __restrict__ misc, sc* __restrict__ a_all, sc* __restrict__ b_all,
                                                        sc* __restrict__ g_all, sc* __restrict__ h_all, const ge* __restrict__ ftab,
@@ -882,7 +889,8 @@ __global__ __launch_bounds__(TAIL_BLK) void k_tail_lr(u32 B, u32 n, u32 prev_rou
     const u32 pj = tid / TAIL_LP, l = tid % TAIL_LP;        // proof slot in the block, lane within the proof
     const u32 p = blockIdx.x * TAIL_PPB + pj;
     const bool live = pj < TAIL_PPB && p < B;
-    const u32 side = l / 33, j = l % 33;                    // j: 0..15 G terms, 16..31 H terms, 32 the B term
+    const u32 side = l / TAIL_LS, rem = l % TAIL_LS;        // lane `rem` of its side: share rem % TAIL_SPLIT of term j
+    const u32 j = rem / TAIL_SPLIT, share = rem % TAIL_SPLIT;  // j: 0..15 G terms, 16..31 H terms, 32 the B term
     const size_t po = live ? (size_t)p : 0;
     sc *a = a_all + po * 2048, *b = b_all + po * 2048, *gg = g_all + po * 2048, *hh = h_all + po * 2048;
     if (prev_round) {
@@ -952,7 +960,8 @@ __global__ __launch_bounds__(TAIL_BLK) void k_tail_lr(u32 B, u32 n, u32 prev_rou
             T = btab;
         }
 #ifndef BBP_KO_TAIL  // (timing experiment, wrong results, when defined)
-        q = ge_scalarmul_pieces(s, T);
+        constexpr int PPS = TAIL_PIECES / TAIL_SPLIT;
+        q = ge_scalarmul_pieces(s, T, (int)share * PPS, (int)share * PPS + PPS);
 #else
         q = T[0];
         q.X.v[0] += (i32)(s.v[0] & 1u);
@@ -961,9 +970,9 @@ __global__ __launch_bounds__(TAIL_BLK) void k_tail_lr(u32 B, u32 n, u32 prev_rou
     const u32* w = reinterpret_cast<const u32*>(&q);
     for (int k = 0; k < GE_WORDS; k++) stage[k * TAIL_BLK + tid] = w[k];
     __syncthreads();
-    // tree sum inside each group of 33 consecutive lanes (one group per proof and side)
-    for (int d = 32; d >= 1; d >>= 1) {
-        if (live && j < (u32)d && j + d < 33) {
+    // tree sum inside each group of TAIL_LS consecutive lanes (one group per proof and side)
+    for (int d = 64; d >= 1; d >>= 1) {
+        if (live && rem < (u32)d && rem + d < (u32)TAIL_LS) {
             ge o;
             u32* ow = reinterpret_cast<u32*>(&o);
             for (int k = 0; k < GE_WORDS; k++) ow[k] = stage[k * TAIL_BLK + tid + d];
@@ -972,7 +981,7 @@ __global__ __launch_bounds__(TAIL_BLK) void k_tail_lr(u32 B, u32 n, u32 prev_rou
         }
         __syncthreads();
     }
-    if (live && j == 0) lrpts[(size_t)p * 2 + side] = q;
+    if (live && rem == 0) lrpts[(size_t)p * 2 + side] = q;
 }
 
 __global__ BBP_LANE_KERNEL void k_ipa_final(u32 B, u32 m, const u32* __restrict__ enc, merlin_transcript* __restrict__ tr, sc* __restrict__ misc,
