@@ -111,6 +111,42 @@ def test_msm_fuzz_half_wavefront_fold(bbp, oc):
         c2.close()
 
 
+@pytest.mark.parametrize("knobs", [{}, {"BBP_SORT_STAGED": "7"}, {"BBP_SORT_STAGED": "0"}])
+def test_msm_sort_oversized_bucket(bbp, oc, knobs):
+    """k_msm_sort_staged places the entries of a window of buckets in an LDS image of 16 384 entries (32 768 for MSMs wider than 3000
+    terms with bit 2 of BBP_SORT_STAGED); a single bucket larger than the image takes a pass of its own with direct stores.  The scalar
+    sum_j 2^(13 j) has 19 NAF digits of magnitude 1: with every term equal to it, bucket 1 holds 19 n entries (55 727 at n = 2933,
+    77 843 at 4097) and every other bucket is empty; a second pattern puts two thirds of the terms there and spreads the rest."""
+    import os
+    old = {k: os.environ.get(k) for k in knobs}
+    os.environ.update(knobs)
+    try:
+        c2 = bbp.Context(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    try:
+        ones = sum(1 << (13 * j) for j in range(19))
+        rnd = random.Random(5)
+        for n_terms, B in ((2933, 3), (2049, 4), (4097, 2)):
+            rows = []
+            for b in range(B):
+                if b % 2 == 0:
+                    row = [ones] * n_terms
+                else:
+                    row = [ones if i % 3 else rnd.randrange(L) for i in range(n_terms)]
+                rows.append(b"".join(rs.sc_bytes(v) for v in row))
+            got = c2.msm_batch(B, n_terms, b"".join(rows), bbp.LAYOUT_BLIND_G_H)
+            exp = oc.msm_layout_many(rows, [n_terms] * B, [bbp.LAYOUT_BLIND_G_H] * B, threads=8)
+            assert got == exp, (knobs, n_terms)
+        assert c2.health() == 0
+    finally:
+        c2.close()
+
+
 @pytest.mark.parametrize("seed", [11, 12])
 def test_prove_verify_fuzz(ctx, bbp, oc, seed):
     rnd = random.Random(seed)
