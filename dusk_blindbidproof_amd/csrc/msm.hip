@@ -213,9 +213,12 @@ __global__ __launch_bounds__(SORT_T) void k_msm_sort(const u32* __restrict__ sca
 // store to its own cache line, bound by L2 write requests (~2 * 10^11 /s).  Here the buckets are walked in windows of at most SORT_CAP
 // entries (consecutive buckets; the window boundaries come from the prefix sums, so every lane finds the same ones): a pass re-walks the
 // lane's NAF digits (cheap), places the entries of the window's buckets in an LDS image with the same LDS atomics as before, and the
-// workgroup then writes the image out as full cache lines.  A bucket larger than the image (adversarial scalars only) takes a pass of
+// workgroup then writes the image out as full cache lines (image: BBP_SORT_CAP entries, 84 KB).  A bucket larger than the image (adversarial scalars only) takes a pass of
 // its own with direct stores.  Entry order inside a bucket differs from the plain kernel's; sums do not care.
-template <int MODE> struct sort_cap { static constexpr u32 V = 16384; };  // image entries (dynamic LDS: 4 bytes each) of an ordinary launch
+#ifndef BBP_SORT_CAP
+#define BBP_SORT_CAP 21504  // two windows for a 2049-term MSM (40.7 k entries), three for 2933 terms; 16 384 (three / four, two workgroups per CU) measured 0.5 % slower per batch
+#endif
+template <int MODE> struct sort_cap { static constexpr u32 V = BBP_SORT_CAP; };  // image entries (dynamic LDS: 4 bytes each) of an ordinary launch
 template <> struct sort_cap<1> { static constexpr u32 V = 8192; };
 constexpr u32 SORT_CAP_WIDE = 32768;  // ... of MSMs with more than SORT_WIDE_FROM terms (one workgroup per CU then)
 constexpr u32 SORT_WIDE_FROM = 3000;
@@ -843,7 +846,7 @@ int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* sc
     const MsmScratch m = msm_scratch_layout(scratch.p, n_work, n_sub, MSM_W, MSM_K);
     {
         ScopedEvent ev(ctx, TAG_MSM_SORT, stream);
-        // staged scatter: 64 KB image (two workgroups per CU) for the prover's 2049- / 2933-term MSMs (three / four windows); wider MSMs (the
+        // staged scatter: 84 KB image for the prover's 2049- / 2933-term MSMs (two / three windows); wider MSMs (the
         // verifier's 4098 terms = 81 k entries: six windows, measured 3 % slower than the plain scatter) get a 128 KB image with bit 2 of the knob
         const bool wide = n_sub > SORT_WIDE_FROM;
         if ((ctx->sort_staged & 1) && (!wide || (ctx->sort_staged & 4))) {
