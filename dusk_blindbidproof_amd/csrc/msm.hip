@@ -22,6 +22,9 @@
 
 namespace bbp {
 
+#ifndef BBP_FOLD_PRIO
+#define BBP_FOLD_PRIO 2  // wave priority of the fold kernels (accumulate: 0, the other thin kernels: 3); 0 / 1 / 3 measured: no difference, 49.4-49.8 ms per batch either way
+#endif
 // resident waves per SIMD the register allocator aims the MSM kernels at (512 VGPRs / waves).  Measured on the blind-bid
 // batch: 2 (no spills) beats 3 and 4 (spills in the cold phases, nothing gained in the issue-bound hot loop).
 #ifndef BBP_MSM_WAVES
@@ -446,7 +449,7 @@ __global__ __launch_bounds__(MSM_T) void k_msm_fold(const u32* __restrict__ curs
     __shared__ u32 xch[GE_WORDS];
     const int tid = threadIdx.x;
     if (n_active && blockIdx.x >= *n_active) return;
-    __builtin_amdgcn_s_setprio(2);
+    __builtin_amdgcn_s_setprio(BBP_FOLD_PRIO);
     const size_t msm = blockIdx.x;
     {
         const u32* cur_in = cursor_all + msm * (size_t)(K + 1);
@@ -629,7 +632,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BBP_FOLD_WAV
     const int tid = threadIdx.x, half = tid >> 5, l = tid & 31;
     const u32 n_tot = n_active ? min(*n_active, n_work) : n_work;
     if (2u * blockIdx.x >= n_tot) return;
-    __builtin_amdgcn_s_setprio(2);
+    __builtin_amdgcn_s_setprio(BBP_FOLD_PRIO);
     const size_t msm = 2 * (size_t)blockIdx.x + half;
     const bool valid = msm < n_tot;  // an odd launch leaves the last upper half idle: it sees an all-empty cursor and adds identities
     u32* cursor = cursor2[half];
