@@ -595,6 +595,22 @@ __device__ __forceinline__ ge ge_shfl_down32(const ge& p, int d) {  // within ea
     return r;
 }
 
+// p + q where p2d = 2 d * p.T is already known (an operand that takes part in several additions pays that product once): 8M
+__device__ __forceinline__ ge ge_add_t2d(const ge& p, const fe& p2d, const ge& q) {
+    fe a = fe_mul(fe_sub(p.Y, p.X), fe_sub(q.Y, q.X));
+    fe b = fe_mul(fe_add(p.Y, p.X), fe_add(q.Y, q.X));
+    fe c = fe_mul(p2d, q.T);
+    fe zz = fe_mul(p.Z, q.Z);
+    fe d = fe_add(zz, zz);
+    fe e = fe_sub(b, a), f = fe_sub(d, c), g = fe_add(d, c), h = fe_add(b, a);
+    ge r;
+    r.X = fe_mul(e, f);
+    r.Y = fe_mul(g, h);
+    r.Z = fe_mul(f, g);
+    r.T = fe_mul(e, h);
+    return r;
+}
+
 __device__ __forceinline__ void park_put(u32* park, int tid, const ge& p) {
     const u32* w = reinterpret_cast<const u32*>(&p);
 #pragma unroll
@@ -679,17 +695,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BBP_FOLD_WAV
 
     // D2. running-sum fold over this lane's 32 buckets (high to low).  Registers are the scarce thing here (this wavefront should fit
     //     beside two accumulate waves: 160 VGPRs): `total` is only touched once per bucket, so it lives in an LDS slot between uses.
+    //     `running` is an operand of both additions of a step: its 2d T product is computed once per change and shared (8 + 8 + 1
+    //     multiplications per bucket instead of 9 + 9).
     ge running = ge_identity();
+    fe r2d = fe_zero();  // 2 d * running.T
     park_put(park, tid, ge_identity());
 #pragma unroll 1
     for (int r = G; r >= 1; r--) {
         const u32 k = (u32)l * G + r;
         if (cursor[k] != cursor[k - 1]) {
             const ge cur = ld_ge(&bsum[k - 1]);
-            running = ge_add(running, cur);
+            running = ge_add_t2d(running, r2d, cur);
+            r2d = fe_mul(running.T, fe_d2());
         }
         const ge total = park_get(park, tid);
-        park_put(park, tid, ge_add(total, running));
+        park_put(park, tid, ge_add_t2d(running, r2d, total));
     }
 
     // E. cross-lane fold inside the half: W = sum_t total_t + G * sum_{t>=1} suffix_t, suffix_t = sum_{u>=t} running_u; result = 2 W - S.
