@@ -87,6 +87,7 @@ struct bbp_ctx {
     hipEvent_t ev_join[MAX_SLICES] = {nullptr, nullptr, nullptr, nullptr}, ev_stagger[MAX_SLICES] = {nullptr, nullptr, nullptr, nullptr};
     int slices = 3;
     int sort_staged = 3;       // bit 0: generic MSMs, bit 1: the generator-fold pass sort with the scatter staged through LDS (msm.hip k_msm_sort_staged; BBP_SORT_STAGED)
+    bool sort_lds_attr = false; // k_msm_sort_staged's dynamic-LDS limit has been raised on this context's device
     int fold_half_from = 512;  // MSM launches with at least this many MSMs fold on half a wavefront per MSM (msm.hip k_msm_fold_half; BBP_FOLD_HALF_FROM)
     int tail_round = bbp::FOLD_ROUND;  // first IPA round run on explicit folded generators (BBP_TAIL_ROUND=12 disables)
     int serial_lds = 160 * 1024;  // LDS the one-lane-per-proof opening kernels reserve to keep their CU to themselves (BBP_SERIAL_LDS, 0 = off)

@@ -874,8 +874,10 @@ int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* sc
         const bool wide = n_sub > SORT_WIDE_FROM;
         if ((ctx->sort_staged & 1) && (!wide || (ctx->sort_staged & 4))) {
             const u32 cap = wide ? SORT_CAP_WIDE : sort_cap<0>::V;
-            static const bool attr_ok = hipFuncSetAttribute((const void*)k_msm_sort_staged<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SORT_CAP_WIDE * 4)) == hipSuccess;
-            (void)attr_ok;
+            if (!ctx->sort_lds_attr) {  // per context = per device: a process may hold one context per GPU (bbp-uds-server --devices)
+                BBP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_msm_sort_staged<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SORT_CAP_WIDE * 4)));
+                ctx->sort_lds_attr = true;
+            }
             hipLaunchKernelGGL(k_msm_sort_staged<0>, dim3(n_work), dim3(SORT_T), cap * 4, stream, scalars_dev, base_idx_dev, n_terms, n_idx_sets, n_sub, split,
                                m.sorted, m.cursor, msm_map_dev, n_active_dev, cap);
         }
