@@ -261,8 +261,29 @@ def main():
     tmax = torch.tensor([dt], device=red_dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        wl.gather(dist, rank, world)  # the path's one collective: proof records / flags to rank 0
     dt = float(tmax.item())
+    # The path's one collective: every rank's proof records / flags to rank 0 in global proof order, after the timed
+    # region.  Timed on its own between barriers -- the first call also builds the point-to-point connections, the second is the
+    # steady-state cost -- and the tensor rank 0 received is CHECKED: a sample from every rank's block against the oracle.
+    gather_info = None
+    if not STUB:
+        gms = []
+        for _ in range(2 if world > 1 else 1):
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+            gathered = wl.gather(dist, rank, world)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            gms.append((time.perf_counter() - t0) * 1e3)
+        if rank == 0 and gathered is not None:
+            if os.environ.get("BBP_BENCH_NO_CHECK") != "1":
+                wl.check_gathered(gathered, world)
+            gather_info = {"gather_ms": gms[-1], "gather_first_ms": gms[0], "bytes": int(gathered.numel()), "ranks": world,
+                           "backend": backend if world > 1 else "none (single rank: local copy)", "checked": "sample of every rank's block vs the C oracle"}
+        del gathered
 
     also = {}
     if args.workload == "prove" and not args.no_also and not STUB:
@@ -294,6 +315,8 @@ def main():
         if not STUB:
             out["roofline"] = roofline(wl, timings, args.steps, alu_peak, dt)
         out.update(wl.extra_report(timings))
+        if gather_info:
+            out["gather"] = gather_info
         if also:
             out["also"] = also
         if world == 1 and not args.no_cpu_baseline and not STUB:

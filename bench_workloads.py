@@ -40,23 +40,46 @@ def _wide(b):
     return (int.from_bytes(b, "little") % L).to_bytes(32, "little")
 
 
+def _bid_row(seed, i, N, sd, dk, w):
+    """One synthetic bid: prover input row, prover entropy, public list, (q, z_img, seed) from its witness row w."""
+    m, x, y, yi, q, z = (w[32 * j:32 * j + 32] for j in range(6))
+    toggle = i % N
+    pub = [_wide(_stream(seed, i, b"pub%d" % j)) for j in range(N)]
+    pub[toggle] = x
+    pub = b"".join(pub)
+    row = dk[:64] + y + yi + q + z + sd + pub + toggle.to_bytes(8, "little")
+    ent = b"".join(_wide(_stream(seed, i, b"ent%d" % j)) for j in range(4 + N)) + _stream(seed, i, b"entseed")[:32]
+    return row, ent, pub, q + z + sd
+
+
+def _bid_dks(seed, i, sd):
+    return _stream(seed, i, b"d")[:8] + bytes(24) + _wide(_stream(seed, i, b"k")) + sd
+
+
 def synth_bids(ctx, B, N, seed):
     """d = uniform u64, k uniform scalar, ONE seed per batch, witness on the device, x_i placed at toggle_i = i mod N."""
     sd = _wide(_stream(seed, 0, b"seed"))
-    dks = b"".join(_stream(seed, i, b"d")[:8] + bytes(24) + _wide(_stream(seed, i, b"k")) + sd for i in range(B))
+    dks = b"".join(_bid_dks(seed, i, sd) for i in range(B))
     w = ctx.witness_batch(dks)
     ins, ents, pubs, qz = [], [], [], []
     for i in range(B):
-        m, x, y, yi, q, z = (w[192 * i + 32 * j:192 * i + 32 * j + 32] for j in range(6))
-        toggle = i % N
-        pub = [_wide(_stream(seed, i, b"pub%d" % j)) for j in range(N)]
-        pub[toggle] = x
-        pub = b"".join(pub)
-        ins.append(dks[96 * i:96 * i + 64] + y + yi + q + z + sd + pub + toggle.to_bytes(8, "little"))
-        ents.append(b"".join(_wide(_stream(seed, i, b"ent%d" % j)) for j in range(4 + N)) + _stream(seed, i, b"entseed")[:32])
+        row, ent, pub, t = _bid_row(seed, i, N, sd, dks[96 * i:96 * i + 96], w[192 * i:192 * i + 192])
+        ins.append(row)
+        ents.append(ent)
         pubs.append(pub)
-        qz.append(q + z + sd)
+        qz.append(t)
     return ins, ents, pubs, qz
+
+
+def oracle_bid_rows(lib, seed, idxs, N):
+    """The same synthetic bids for the rows `idxs` of the batch seeded `seed`, made WITHOUT the engine (witness by the C oracle):
+    what rank 0 needs to check records gathered from another rank, whose inputs it never held."""
+    sd = _wide(_stream(seed, 0, b"seed"))
+    out = []
+    for i in idxs:
+        dk = _bid_dks(seed, i, sd)
+        out.append(_bid_row(seed, i, N, sd, dk, lib.witness(dk)))
+    return out
 
 
 def _to_dev(torch, device, data):
@@ -105,7 +128,11 @@ class _Base:
         return {"kernels_us": _kernel_table(timings)}
 
     def gather(self, dist, rank, world):
-        pass
+        """The path's one collective: this rank's results to rank 0, in global proof order; rank 0 gets the tensor, others None."""
+        return None
+
+    def check_gathered(self, gathered, world):
+        """Rank 0, outside the timed region: a sample from EVERY rank's block of the gathered results against the oracle."""
 
     def drain(self):
         pass
@@ -137,7 +164,7 @@ class MsmWorkload(_Base):
     unit = "proofs/s"
 
     def __init__(self, ctx, bbp, torch, device, batch, items, seed):
-        self.ctx, self.bbp, self.torch, self.B = ctx, bbp, torch, batch
+        self.ctx, self.bbp, self.torch, self.B, self.seed = ctx, bbp, torch, batch, seed
         self.n1 = 1442 + 3 * items
         self.shapes = [(1 + 2 * self.n1, bbp.LAYOUT_BLIND_G_H), (1 + self.n1, bbp.LAYOUT_BLIND_G),
                        (1 + 2 * self.n1, bbp.LAYOUT_BLIND_G_H)]
@@ -168,8 +195,23 @@ class MsmWorkload(_Base):
                     raise SystemExit("PARITY FAILURE in bench msm workload row %d" % r)
 
     def gather(self, dist, rank, world):
-        t = self.out[0]
-        dist.gather(t, [self.torch.empty_like(t) for _ in range(world)] if rank == 0 else None, dst=0)
+        from dusk_blindbidproof_amd import sharding
+        rec = self.torch.cat(self.out, dim=1).contiguous().view(-1)  # per proof: A_I1 || A_O1 || S1, 96 bytes
+        return sharding.gather_records(dist, rec, 96, self.B * world, rank, world)
+
+    def check_gathered(self, gathered, world):
+        from bench import synth_scalars_device
+        lib = _oracle_lib()
+        got = bytes(gathered.cpu().numpy().tobytes())
+        for r in range(world):  # rank r's scalars are regenerated here from its seed (same generator, same device type)
+            for i, (n, layout) in enumerate(self.shapes):
+                s = synth_scalars_device(self.torch, self.B, n, (self.seed + r) * 16 + i, self.scal[0].device)
+                for row in (0, self.B - 1):
+                    exp = lib.msm_layout(bytes(s[row].cpu().numpy().tobytes()), n, layout)
+                    o = 96 * (r * self.B + row) + 32 * i
+                    if got[o:o + 32] != exp:
+                        raise SystemExit("PARITY FAILURE in gathered msm results: rank %d row %d msm %d" % (r, row, i))
+                del s
 
     def cpu_baseline(self):
         lib = _oracle_lib()
@@ -191,7 +233,7 @@ class ProveWorkload(_Base):
     unit = "proofs/s"
 
     def __init__(self, ctx, bbp, torch, device, batch, items, seed):
-        self.ctx, self.bbp, self.torch, self.B, self.N, self.device = ctx, bbp, torch, batch, items, device
+        self.ctx, self.bbp, self.torch, self.B, self.N, self.device, self.seed = ctx, bbp, torch, batch, items, device, seed
         self.ins, self.ents, self.pubs, self.qz = synth_bids(ctx, batch, items, seed)
         self.in_dev = _to_dev(torch, device, b"".join(self.ins))
         self.ent_dev = _to_dev(torch, device, b"".join(self.ents))
@@ -239,6 +281,22 @@ class ProveWorkload(_Base):
         """The one collective of the path: fixed-stride proof records to rank 0 (RCCL over xGMI)."""
         from dusk_blindbidproof_amd import sharding
         return sharding.gather_records(dist, self.out_dev, self.rec, self.B * world, rank, world)
+
+    def check_gathered(self, gathered, world):
+        """Records as rank 0 received them: the first, a middle and the last record of EVERY rank's block byte-equal to what the
+        C oracle proves from that rank's inputs (re-made here from the rank's seed, witness by the oracle) and accepted by it."""
+        lib = _oracle_lib()
+        got = bytes(gathered.cpu().numpy().tobytes())
+        assert len(got) == self.B * world * self.rec
+        idxs = sorted({0, self.B // 2, self.B - 1})
+        for r in range(world):
+            for i, (row, ent, pub, qz) in zip(idxs, oracle_bid_rows(lib, self.seed + r, idxs, self.N)):
+                rc, exp = lib.prove(row[:224], row[224:224 + 32 * self.N], int.from_bytes(row[-8:], "little"), ent)
+                rec = got[(r * self.B + i) * self.rec:(r * self.B + i + 1) * self.rec]
+                if rc != 0 or rec != exp:
+                    raise SystemExit("PARITY FAILURE in gathered records: rank %d record %d" % (r, i))
+                if lib.verify(rec, qz[:32], qz[32:64], qz[64:96], pub) != 0:
+                    raise SystemExit("oracle verifier rejected gathered record: rank %d record %d" % (r, i))
 
     def cpu_baseline(self):
         lib = _oracle_lib()
@@ -325,6 +383,16 @@ class VerifyWorkload(_Base):
     def gather(self, dist, rank, world):
         from dusk_blindbidproof_amd import sharding
         return sharding.gather_records(dist, self.status.view(self.torch.uint8), 4, self.B * world, rank, world)
+
+    def check_gathered(self, gathered, world):
+        """Flags as rank 0 received them: in EVERY rank's block exactly the known corrupted indices are rejected (every rank corrupts
+        the same positions of its own proofs; rank 0's rows were also put to the oracle by check())."""
+        st = gathered.cpu().view(self.torch.int32).tolist()
+        assert len(st) == self.B * world
+        for r in range(world):
+            blk = st[r * self.B:(r + 1) * self.B]
+            if [i for i, v in enumerate(blk) if v != 0] != self.bad or any(blk[i] not in (1, 3) for i in self.bad):
+                raise SystemExit("gathered verify flags: rank %d block differs from the expected pattern" % r)
 
     def cpu_baseline(self):
         lib = _oracle_lib()
@@ -493,6 +561,11 @@ class StreamWorkload(_Base):
         from dusk_blindbidproof_amd import sharding
         sl = self.slots[(self.k - 1) % self.depth]
         return sharding.gather_records(dist, sl["d_st"].view(self.torch.uint8), 4, self.B * world, rank, world)
+
+    def check_gathered(self, gathered, world):
+        st = gathered.cpu().view(self.torch.int32)
+        if st.numel() != self.B * world or int((st != 0).sum()):
+            raise SystemExit("gathered stream flags: %d failed verifications" % int((st != 0).sum()))
 
     def cpu_baseline(self):
         lib = _oracle_lib()

@@ -122,3 +122,48 @@ def test_msm_dev_noncanonical_scalars_do_not_fault(ctx, bbp):
     assert out[:32] == rs.encode(rs.msm(good, _bases(bbp.LAYOUT_BLIND_G_H, n_terms, bbp)))
     for b in range(1, B):
         assert rs.decode(out[32 * b:32 * b + 32]) is not None  # still a valid group element
+
+
+def test_config2_msm_only_batch_1024(ctx, bbp, built):
+    """BASELINE.json configs[1] AT ITS STATED SIZE: a batch of 1024 blind-bid proofs, Pippenger MSM kernel only -- per proof the
+    three commitment MSMs A_I1 / A_O1 / S1 (2933 + 1467 + 2933 terms at N = 8, SURVEY.md 8d "Config 2"), through
+    bbp_msm_batch_dev with the scalars resident in HBM, "bit-exact check vs CPU":
+      * 16 rows of every launch (first, last, 14 spread) byte-equal to the C oracle's msm_layout (vartime Pippenger / Straus, own
+        field arithmetic), and
+      * a size-independent property over ALL 1024 rows of every launch: rows b and 512 + b differ by one fixed scalar vector t,
+        so P[512 + b] - P[b] = MSM(t) for every b (linearity), with MSM(t) itself taken from the big-int oracle."""
+    import torch
+    from tests import oracle_c
+    oc = oracle_c.load(built.build_oracle())
+    dev = torch.device("cuda", 0)
+    B, half = 1024, 512
+    shapes = [(2933, bbp.LAYOUT_BLIND_G_H), (1467, bbp.LAYOUT_BLIND_G), (2933, bbp.LAYOUT_BLIND_G_H)]
+    for which, (n_terms, layout) in enumerate(shapes):
+        rnd = random.Random(1000 + which)
+        t = [rnd.randrange(L) for _ in range(n_terms)]
+        base = [[rnd.getrandbits(252) for _ in range(n_terms)] for _ in range(half)]  # < 2^252 < l: canonical
+        if which == 0:  # witness-like rows as the prover's a_L / a_R are: booleans, zeros, small values among full-size scalars
+            base[3] = [(i % 2) if i % 5 else base[3][i] for i in range(n_terms)]
+            base[4] = [0] * n_terms
+        rows = base + [[(a + b) % L for a, b in zip(row, t)] for row in base]
+        buf = b"".join(v.to_bytes(32, "little") for row in rows for v in row)
+        d_in = torch.frombuffer(bytearray(buf), dtype=torch.uint8).to(dev)
+        d_out = torch.zeros(B * 32, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        ctx.msm_batch_dev(B, n_terms, d_in.data_ptr(), layout, d_out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        out = bytes(d_out.cpu().numpy().tobytes())
+        # (a) sampled rows against the C oracle
+        sample = sorted({0, 3, 4, B - 1, half - 1, half, half + 3, half + 4} | {(73 * j + 11) % B for j in range(10)})
+        assert len(sample) >= 16
+        stride = 32 * n_terms
+        exp = oc.msm_layout_many([buf[r * stride:(r + 1) * stride] for r in sample], [n_terms] * len(sample), [layout] * len(sample), 8)
+        for j, r in enumerate(sample):
+            assert out[32 * r:32 * r + 32] == exp[32 * j:32 * j + 32], (which, r)
+        assert out[32 * 4:32 * 5] == bytes(32) if which == 0 else True  # the all-zero row is the identity
+        # (b) linearity over every row of the launch
+        pt_t = rs.msm(t, _bases(layout, n_terms, bbp))
+        pts = [rs.decode(out[32 * b:32 * b + 32]) for b in range(B)]
+        assert all(p is not None for p in pts), which
+        for b in range(half):
+            assert rs.pt_eq(rs.pt_add(pts[half + b], rs.pt_neg(pts[b])), pt_t), (which, b)
