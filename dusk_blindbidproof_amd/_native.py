@@ -22,6 +22,11 @@ _vp, _u32, _i32, _u64, _cp = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int32, c
 SIGNATURES = {
     "bbp_init": (_i32, [_i32, ctypes.POINTER(_vp)]),
     "bbp_free": (None, [_vp]),
+    "bbp_init_all": (_i32, [ctypes.POINTER(_vp)]),
+    "bbp_pool_init": (_i32, [ctypes.POINTER(_i32), _u32, ctypes.POINTER(_vp)]),
+    "bbp_pool_size": (_u32, [_vp]),
+    "bbp_pool_member": (_vp, [_vp, _u32]),
+    "bbp_pool_member_stats": (_i32, [_vp, _u32, ctypes.POINTER(_u64), ctypes.POINTER(_u64)]),
     "bbp_last_error": (_cp, [_vp]),
     "bbp_context_stream": (_vp, [_vp]),
     "bbp_context_copy_stream": (_vp, [_vp]),
@@ -32,6 +37,8 @@ SIGNATURES = {
     "bbp_msm_batch_dev": (_i32, [_vp, _u32, _u32, _vp, _u32, _vp, _vp]),
     "bbp_witness_batch": (_i32, [_vp, _u32, _vp, _vp]),
     "bbp_prove": (_i32, [_vp, _vp, _vp, _u32, _u64, _vp, _vp, ctypes.POINTER(_u32)]),
+    "bbp_prove_async": (_i32, [_vp, _vp, _vp, _u32, _u64, _vp, _vp, _vp, _vp]),
+    "bbp_verify_async": (_i32, [_vp, _vp, _u32, _vp, _vp, _vp, _vp, _u32, _vp, _vp]),
     "bbp_proof_record_size": (_u32, [_u32]),
     "bbp_entropy_size": (_u32, [_u32]),
     "bbp_verify": (_i32, [_vp, _vp, _u32, _vp, _vp, _vp, _vp, _u32]),
@@ -51,6 +58,9 @@ SIGNATURES = {
     "bbp_set_profiling": (_i32, [_vp, _i32]),
     "bbp_last_timings": (_i32, [_vp, _vp, _u32, ctypes.POINTER(_u32)]),
 }
+
+
+DONE_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int32)  # bbp_done_fn
 
 
 class BbpError(RuntimeError):
@@ -100,9 +110,13 @@ class Context:
     """One engine context per GPU (bbp_init). Mirrors the reference's implicit process-wide state
     (lazy_static CONSTANTS + generate_cs_transcript, src/blindbid/mod.rs:7-40) as an explicit handle."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, _borrowed=None):
+        if _borrowed is not None:  # a pool member: owned by its pool, never freed from here
+            self._h, self._owned = ctypes.c_void_p(_borrowed), False
+            return
+        self._owned = True
         self._h = ctypes.c_void_p()
-        rc = lib.bbp_init(device, ctypes.byref(self._h))
+        rc = self._init(device)
         if rc != 0:
             msg = lib.bbp_last_error(self._h).decode() if self._h else "no usable HIP device"
             if self._h:
@@ -110,9 +124,13 @@ class Context:
                 self._h = None
             raise BbpError(rc, msg)
 
+    def _init(self, device):
+        return lib.bbp_init(device, ctypes.byref(self._h))
+
     def close(self):
         if getattr(self, "_h", None):
-            lib.bbp_free(self._h)
+            if getattr(self, "_owned", True):
+                lib.bbp_free(self._h)
             self._h = None
 
     def __del__(self):
@@ -179,6 +197,29 @@ class Context:
         n = len(pub_list) // 32
         return lib.bbp_verify(self._h, _buf(record), len(record), _buf(score), _buf(z_img), _buf(seed),
                               _buf(pub_list) if n else None, n)
+
+    def prove_async(self, scalars7, pub_list, toggle, entropy, on_done):
+        """bbp_prove_async: returns at once; on_done(status, record_bytes_or_None) is called on an engine thread.  The returned
+        object keeps the buffers and the ctypes callback alive: hold it until on_done has run."""
+        n = len(pub_list) // 32
+        out = (ctypes.c_uint8 * record_size(max(n, 1)))()
+
+        def _cb(_user, status):
+            on_done(status, bytes(out)[:record_size(n)] if status == 0 else None)
+        cb = DONE_FN(_cb)
+        ent = _buf(entropy) if entropy is not None else None
+        self._check(lib.bbp_prove_async(self._h, _buf(scalars7), _buf(pub_list), n, toggle, ent, out, cb, None))
+        return (cb, out)
+
+    def verify_async(self, record, score, z_img, seed, pub_list, on_done):
+        """bbp_verify_async: on_done(status) on an engine thread -- or at once, from this call, when the host-side structural
+        parse already decides (the C call then returns the status and never calls back)."""
+        n = len(pub_list) // 32
+        cb = DONE_FN(lambda _user, status: on_done(status))
+        rc = lib.bbp_verify_async(self._h, _buf(record), len(record), _buf(score), _buf(z_img), _buf(seed), _buf(pub_list), n, cb, None)
+        if rc != 0:
+            on_done(rc)
+        return cb
 
     def prove_batch(self, B, N, inputs, entropy=None):
         out = (ctypes.c_uint8 * (B * record_size(N)))()
@@ -260,3 +301,35 @@ class Context:
         n = ctypes.c_uint32()
         self._check(lib.bbp_last_timings(self._h, arr, cap, ctypes.byref(n)))
         return [(int(arr[i]), float(arr[i + 1])) for i in range(0, n.value, 2)]
+
+
+class Pool(Context):
+    """A device pool (include/bbp.h "Device pool"): one handle, one engine context per GPU behind it.  Takes the host-pointer
+    calls of Context -- prove / verify (combined and dealt to the least-loaded member), prove_batch / verify_batch /
+    verify_batch_aggregated / msm_batch (block-split over the members, results in request order); the device-pointer calls
+    need a member (`pool.member(i)`).  devices=None -> every visible GPU (bbp_init_all)."""
+
+    def __init__(self, devices=None):
+        self._devices = None if devices is None else list(devices)
+        super().__init__(0)
+
+    def _init(self, _device):
+        if self._devices is None:
+            return lib.bbp_init_all(ctypes.byref(self._h))
+        arr = (ctypes.c_int32 * len(self._devices))(*self._devices)
+        return lib.bbp_pool_init(arr, len(self._devices), ctypes.byref(self._h))
+
+    def __len__(self):
+        return lib.bbp_pool_size(self._h)
+
+    def member(self, i):
+        h = lib.bbp_pool_member(self._h, i)
+        if not h:
+            raise IndexError(i)
+        return Context(_borrowed=h)
+
+    def member_stats(self, i):
+        """(combined prove / verify device calls dealt to member i, requests they carried)"""
+        a, b = ctypes.c_uint64(), ctypes.c_uint64()
+        self._check(lib.bbp_pool_member_stats(self._h, i, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value

@@ -81,6 +81,7 @@ extern "C" int32_t bbp_msm_batch_dev(bbp_ctx* ctx, uint32_t B, uint32_t n_terms,
                                      void* out32_dev, void* stream_) {
     if (!ctx || !scalars_dev || !out32_dev) return BBP_ERR_BAD_ARG;
     if (B == 0) return BBP_OK;
+    if (is_pool(ctx)) return pool_reject(ctx, "bbp_msm_batch_dev");
     return api_guard(ctx, [&]() -> int32_t { return msm_batch_dev(ctx, B, n_terms, scalars_dev, layout, out32_dev, pick_stream(ctx, stream_)); });
 }
 
@@ -88,6 +89,13 @@ extern "C" int32_t bbp_msm_batch(bbp_ctx* ctx, uint32_t B, uint32_t n_terms, con
                                  uint8_t* out32) {
     if (!ctx || !scalars || !out32) return BBP_ERR_BAD_ARG;
     if (B == 0) return BBP_OK;
+    if (is_pool(ctx)) {  // block split over the members (pool.cpp)
+        try {
+            return pool_msm_batch(ctx, B, n_terms, scalars, layout, out32);
+        } catch (...) {
+            return BBP_ERR_INTERNAL;
+        }
+    }
     return api_guard(ctx, [&]() -> int32_t {
         BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
         // canonical scalars only (the reference's Scalars are always reduced)

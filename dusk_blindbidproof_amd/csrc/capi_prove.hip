@@ -112,6 +112,10 @@ std::string& tls_error() {
     static thread_local std::string e;
     return e;
 }
+const void*& tls_error_owner() {
+    static thread_local const void* c = nullptr;
+    return c;
+}
 int32_t fault_injected(const char* site) {
     const char* e = getenv("BBP_FAULT_INJECT");
     if (e && strcmp(e, site) == 0) throw std::runtime_error(std::string("injected fault at ") + site);
@@ -120,16 +124,17 @@ int32_t fault_injected(const char* site) {
 }
 // entry points without a context to lock still keep every exception on this side of the boundary
 template <class F>
-static int32_t no_throw(F&& body) noexcept {
+static int32_t no_throw(F&& body, const void* ctx = nullptr) noexcept {
     try {
         return body();
     } catch (const std::invalid_argument& e) {
-        try { tls_error() = std::string("invalid argument: ") + e.what(); } catch (...) {}
+        try { set_tls_error(ctx, std::string("invalid argument: ") + e.what()); } catch (...) {}
         return BBP_ERR_BAD_ARG;
     } catch (const std::exception& e) {
-        try { tls_error() = std::string("internal error: ") + e.what(); } catch (...) {}
+        try { set_tls_error(ctx, std::string("internal error: ") + e.what()); } catch (...) {}
         return BBP_ERR_INTERNAL;
     } catch (...) {
+        set_tls_error(ctx, "internal error: unknown exception");
         return BBP_ERR_INTERNAL;
     }
 }
@@ -152,6 +157,7 @@ extern "C" int32_t bbp_debug_compile_circuit(uint32_t N, uint32_t* n_mul, uint32
 extern "C" int32_t bbp_witness_batch(bbp_ctx* ctx, uint32_t B, const uint8_t* dks, uint8_t* out) {
     if (!ctx || !dks || !out) return BBP_ERR_BAD_ARG;
     if (B == 0) return BBP_OK;
+    if (is_pool(ctx)) return bbp_witness_batch(ctx->members[0], B, dks, out);  // microseconds of work: one member does it
     return api_guard(ctx, [&]() -> int32_t {
         BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
         int32_t rc;
@@ -186,6 +192,7 @@ static int32_t check_n(bbp_ctx* ctx, uint32_t N) {
 extern "C" int32_t bbp_prepare_bids_dev(bbp_ctx* ctx, uint32_t B, uint32_t N, const void* bids_dev, const void* lists_dev,
                                         const void* toggles_dev, void* prove_in_dev, void* verify_tail_dev, void* stream) {
     if (!ctx || !bids_dev || !lists_dev || !toggles_dev || !prove_in_dev) return BBP_ERR_BAD_ARG;
+    if (is_pool(ctx)) return pool_reject(ctx, "bbp_prepare_bids_dev");
     return api_guard(ctx, [&]() -> int32_t {
         int32_t rc = check_n(ctx, N);
         if (rc) return rc;
@@ -276,7 +283,8 @@ static int32_t upload_inputs(bbp_ctx* ctx, bbp_ctx::IoSlot& sl, const uint8_t* a
 // -- would queue up behind it (measured: the input copy "took" 87 ms, i.e. the previous batch's whole MSM stage; two host
 // threads got no overlap at all).  Issued after the wait, either copy takes ~0.2 ms whatever the compute queues are doing.
 static int32_t fetch_results(bbp_ctx* ctx, bbp_ctx::IoSlot& sl, size_t bytes) {
-    hipError_t e = wait_event_polling(sl.ev);
+    hipError_t e = hipSetDevice(ctx->device);  // the lock is not held here and nothing has set this thread's device yet (pool workers)
+    if (e == hipSuccess) e = wait_event_polling(sl.ev);
     if (e == hipSuccess) e = hipMemcpyAsync(sl.h_out, sl.out.p, bytes, hipMemcpyDeviceToHost, ctx->copy);
     if (e == hipSuccess) e = hipEventRecord(sl.ev_in, ctx->copy);
     if (e == hipSuccess) e = wait_event_polling(sl.ev_in);
@@ -398,12 +406,18 @@ static int32_t no_throw_ctx(bbp_ctx* ctx, F&& body) noexcept {  // for bodies th
 extern "C" int32_t bbp_prove_batch(bbp_ctx* ctx, uint32_t B, uint32_t N, const uint8_t* in, const uint8_t* entropy, uint8_t* out,
                                    int32_t* status) {
     if (!ctx || !in || !out || !status) return BBP_ERR_BAD_ARG;
+    if (is_pool(ctx)) {  // block split over the members, records in request order (pool.cpp)
+        const int32_t rc = api_guard(ctx, [&]() -> int32_t { return check_n(ctx, N); });
+        if (rc || B == 0) return rc;
+        return no_throw_ctx(ctx, [&]() -> int32_t { return pool_prove_batch(ctx, B, N, in, entropy, out, status); });
+    }
     return no_throw_ctx(ctx, [&]() -> int32_t { return prove_batch_host(ctx, B, N, in, entropy, out, status); });
 }
 
 extern "C" int32_t bbp_prove_batch_dev(bbp_ctx* ctx, uint32_t B, uint32_t N, const void* in_dev, const void* entropy_dev, void* out_dev,
                                        void* stream) {
     if (!ctx || !in_dev || !entropy_dev || !out_dev) return BBP_ERR_BAD_ARG;
+    if (is_pool(ctx)) return pool_reject(ctx, "bbp_prove_batch_dev");
     return api_guard(ctx, [&]() -> int32_t {
         int32_t rc = check_n(ctx, N);
         if (rc) return rc;
@@ -421,6 +435,29 @@ int32_t bbp::prove_batch_locked(bbp_ctx* ctx, uint32_t B, uint32_t N, const uint
     return rc;
 }
 
+// completion hook of the asynchronous entry points (runs on a combiner thread): the request's message becomes that thread's
+// bbp_last_error text for the duration of the callback, then the request is gone
+static void async_done(Request* r) {
+    try {
+        set_tls_error(r->origin, r->status == BBP_OK ? std::string() : !r->err.empty() ? r->err : r->status == BBP_ERR_BAD_ARG ? "toggle >= N"
+                                     : r->status == BBP_ERR_FORMAT && r->kind == 0 ? "non-canonical scalar input"
+                                                                                    : status_text(r->status));
+    } catch (...) {
+    }
+    void (*fn)(void*, int32_t) = r->user_fn;
+    void* user = r->user;
+    const int32_t st = r->status;
+    delete r;
+    fn(user, st);
+}
+
+static void fill_prove_input(std::vector<uint8_t>& in, const uint8_t scalars7[7 * 32], const uint8_t* pub_list, uint32_t N, uint64_t toggle) {
+    in.resize(7 * 32 + (size_t)N * 32 + 8);
+    memcpy(&in[0], scalars7, 7 * 32);
+    memcpy(&in[7 * 32], pub_list, (size_t)N * 32);
+    memcpy(&in[7 * 32 + (size_t)N * 32], &toggle, 8);
+}
+
 extern "C" int32_t bbp_prove(bbp_ctx* ctx, const uint8_t scalars7[7 * 32], const uint8_t* pub_list, uint32_t N, uint64_t toggle,
                              const uint8_t* entropy, uint8_t* proof_out, uint32_t* proof_len) {
     if (!ctx || !scalars7 || !proof_out) return BBP_ERR_BAD_ARG;
@@ -428,10 +465,8 @@ extern "C" int32_t bbp_prove(bbp_ctx* ctx, const uint8_t scalars7[7 * 32], const
     if (rc) return rc;
     if (!pub_list) return BBP_ERR_BAD_ARG;
     return no_throw([&]() -> int32_t {
-        std::vector<uint8_t> in(7 * 32 + (size_t)N * 32 + 8);
-        memcpy(&in[0], scalars7, 7 * 32);
-        memcpy(&in[7 * 32], pub_list, (size_t)N * 32);
-        memcpy(&in[7 * 32 + (size_t)N * 32], &toggle, 8);
+        std::vector<uint8_t> in;
+        fill_prove_input(in, scalars7, pub_list, N, toggle);
         Request r;
         r.kind = 0;
         r.N = N;
@@ -441,12 +476,43 @@ extern "C" int32_t bbp_prove(bbp_ctx* ctx, const uint8_t scalars7[7 * 32], const
         r.out = proof_out;
         const int32_t st = static_cast<Combiner*>(ctx->combiner)->submit(ctx, r);
         if (st != BBP_OK) {
-            tls_error() = !r.err.empty() ? r.err : st == BBP_ERR_BAD_ARG ? "toggle >= N" : "non-canonical scalar input";
+            set_tls_error(ctx, !r.err.empty() ? r.err : st == BBP_ERR_BAD_ARG ? "toggle >= N" : "non-canonical scalar input");
             return st;
         }
         if (proof_len) *proof_len = BBP_R1CS_PROOF_BYTES;
         return BBP_OK;
-    });
+    }, ctx);
+}
+
+extern "C" int32_t bbp_prove_async(bbp_ctx* ctx, const uint8_t scalars7[7 * 32], const uint8_t* pub_list, uint32_t N, uint64_t toggle,
+                                   const uint8_t* entropy, uint8_t* proof_out, bbp_done_fn done, void* user) {
+    if (!ctx || !scalars7 || !proof_out || !done) return BBP_ERR_BAD_ARG;
+    int32_t rc = api_guard(ctx, [&]() -> int32_t { return check_n(ctx, N); });
+    if (rc) return rc;
+    if (!pub_list) return BBP_ERR_BAD_ARG;
+    return no_throw([&]() -> int32_t {
+        Request* r = new Request();
+        r->kind = 0;
+        r->N = N;
+        fill_prove_input(r->own_in, scalars7, pub_list, N, toggle);  // inputs are copied: the caller's buffers are free on return
+        r->in = r->own_in.data();
+        r->in_len = r->own_in.size();
+        if (entropy) {
+            r->own_entropy.assign(entropy, entropy + bbp_entropy_size(N));
+            r->entropy = r->own_entropy.data();
+        }
+        r->out = proof_out;
+        r->on_done = async_done;
+        r->origin = ctx;
+        r->user_fn = done;
+        r->user = user;
+        if (!static_cast<Combiner*>(ctx->combiner)->submit_async(ctx, r)) {
+            delete r;
+            set_tls_error(ctx, "call combiner: cannot start a batch thread");
+            return BBP_ERR_INTERNAL;
+        }
+        return BBP_OK;
+    }, ctx);
 }
 
 // rec_ver 0: compact 1121-byte proofs; 1: the 2-phase 1217-byte R1CSProof layout (both parse in the reference)
@@ -501,12 +567,14 @@ extern "C" int32_t bbp_verify_batch(bbp_ctx* ctx, uint32_t B, uint32_t N, const 
     if (!ctx || !in || !status) return BBP_ERR_BAD_ARG;
     int32_t rc = api_guard(ctx, [&]() -> int32_t { return check_n(ctx, N); });
     if (rc || B == 0) return rc;
+    if (is_pool(ctx)) return no_throw_ctx(ctx, [&]() -> int32_t { return pool_verify_batch(ctx, B, N, in, status, false, 0, nullptr); });
     return no_throw_ctx(ctx, [&]() -> int32_t { return verify_batch_host(ctx, B, N, 0, in, status); });
 }
 
 extern "C" int32_t bbp_verify_batch_dev(bbp_ctx* ctx, uint32_t B, uint32_t N, const void* in_dev, const void* entropy_dev,
                                         void* status_dev, void* stream) {
     if (!ctx || !in_dev || !entropy_dev || !status_dev) return BBP_ERR_BAD_ARG;
+    if (is_pool(ctx)) return pool_reject(ctx, "bbp_verify_batch_dev");
     return api_guard(ctx, [&]() -> int32_t {
         int32_t rc = check_n(ctx, N);
         if (rc) return rc;
@@ -522,6 +590,8 @@ extern "C" int32_t bbp_verify_batch_aggregated(bbp_ctx* ctx, uint32_t B, uint32_
     if (!ctx || !in || !status) return BBP_ERR_BAD_ARG;
     int32_t rc = api_guard(ctx, [&]() -> int32_t { return check_n(ctx, N); });
     if (rc || B == 0) return rc;
+    if (is_pool(ctx))
+        return no_throw_ctx(ctx, [&]() -> int32_t { return pool_verify_batch(ctx, B, N, in, status, true, group ? group : BBP_AGG_GROUP_DEFAULT, n_fallback); });
     return no_throw_ctx(ctx, [&]() -> int32_t { return verify_batch_host(ctx, B, N, 0, in, status, group ? group : BBP_AGG_GROUP_DEFAULT, n_fallback); });
 }
 
@@ -529,6 +599,7 @@ extern "C" int32_t bbp_verify_batch_aggregated_dev(bbp_ctx* ctx, uint32_t B, uin
                                                    void* status_dev, uint32_t group, uint32_t* n_fallback, void* stream) {
     if (n_fallback) *n_fallback = 0;
     if (!ctx || !in_dev || !entropy_dev || !status_dev) return BBP_ERR_BAD_ARG;
+    if (is_pool(ctx)) return pool_reject(ctx, "bbp_verify_batch_aggregated_dev");
     return api_guard(ctx, [&]() -> int32_t {
         int32_t rc = check_n(ctx, N);
         if (rc) return rc;
@@ -539,15 +610,11 @@ extern "C" int32_t bbp_verify_batch_aggregated_dev(bbp_ctx* ctx, uint32_t B, uin
     });
 }
 
-extern "C" int32_t bbp_verify(bbp_ctx* ctx, const uint8_t* record, uint32_t record_len, const uint8_t score[32], const uint8_t z_img[32],
-                              const uint8_t seed[32], const uint8_t* pub_list, uint32_t N) {
-    if (!ctx || !record || !score || !z_img || !seed) return BBP_ERR_BAD_ARG;
-    int32_t rc = api_guard(ctx, [&]() -> int32_t { return check_n(ctx, N); });
-    if (rc) return rc;
-    if (!pub_list) return BBP_ERR_BAD_ARG;
-    // Structural parse exactly as R1CSProof::from_bytes / InnerProductProof::from_bytes order their checks:
-    // a record of any length is either a FormatError, or well formed with a wrong IPA depth (-> VerificationError from
-    // verification_scalars, n != 2^lg_n), or one of the two layouts the device kernels take.
+// Structural parse exactly as R1CSProof::from_bytes / InnerProductProof::from_bytes order their checks: a record of
+// any length is either a FormatError, or well formed with a wrong IPA depth (-> VerificationError from verification_scalars,
+// n != 2^lg_n), or one of the two layouts the device kernels take (*ver).  BBP_OK = hand it to the device.
+static int32_t screen_verify_args(const uint8_t* record, uint32_t record_len, const uint8_t score[32], const uint8_t z_img[32],
+                                  const uint8_t seed[32], uint32_t N, uint8_t* ver_out) {
     const uint32_t tail = 32u * (4u + N);
     if (record_len < tail + 1u) return BBP_ERR_FORMAT;
     const uint32_t plen = record_len - tail;
@@ -575,13 +642,34 @@ extern "C" int32_t bbp_verify(bbp_ctx* ctx, const uint8_t* record, uint32_t reco
         if (!sc_is_canonical(w)) return BBP_ERR_FORMAT;
     }
     if (lg_n != 11u) return BBP_ERR_VERIFY;  // padded_n = 2048 != 2^lg_n
+    *ver_out = ver;
+    return BBP_OK;
+}
+
+static void fill_verify_input(std::vector<uint8_t>& in, const uint8_t* record, uint32_t record_len, const uint8_t score[32],
+                              const uint8_t z_img[32], const uint8_t seed[32], const uint8_t* pub_list, uint32_t N) {
+    in.resize((size_t)record_len + 96 + (size_t)N * 32);
+    memcpy(&in[0], record, record_len);
+    memcpy(&in[record_len], score, 32);
+    memcpy(&in[record_len + 32], z_img, 32);
+    memcpy(&in[record_len + 64], seed, 32);
+    memcpy(&in[record_len + 96], pub_list, (size_t)N * 32);
+}
+
+extern "C" int32_t bbp_verify(bbp_ctx* ctx, const uint8_t* record, uint32_t record_len, const uint8_t score[32], const uint8_t z_img[32],
+                              const uint8_t seed[32], const uint8_t* pub_list, uint32_t N) {
+    if (!ctx || !record || !score || !z_img || !seed) return BBP_ERR_BAD_ARG;
+    int32_t rc = api_guard(ctx, [&]() -> int32_t { return check_n(ctx, N); });
+    if (rc) return rc;
+    if (!pub_list) return BBP_ERR_BAD_ARG;
+    uint8_t ver = 0;
+    if ((rc = screen_verify_args(record, record_len, score, z_img, seed, N, &ver))) {
+        set_tls_error(ctx, rc == BBP_ERR_FORMAT ? "malformed proof record or non-canonical public scalar" : "inner-product proof of the wrong depth");
+        return rc;
+    }
     return no_throw([&]() -> int32_t {
-        std::vector<uint8_t> in((size_t)record_len + 96 + (size_t)N * 32);
-        memcpy(&in[0], record, record_len);
-        memcpy(&in[record_len], score, 32);
-        memcpy(&in[record_len + 32], z_img, 32);
-        memcpy(&in[record_len + 64], seed, 32);
-        memcpy(&in[record_len + 96], pub_list, (size_t)N * 32);
+        std::vector<uint8_t> in;
+        fill_verify_input(in, record, record_len, score, z_img, seed, pub_list, N);
         Request r;
         r.kind = 1;
         r.N = N;
@@ -589,9 +677,39 @@ extern "C" int32_t bbp_verify(bbp_ctx* ctx, const uint8_t* record, uint32_t reco
         r.in = in.data();
         r.in_len = in.size();
         const int32_t st = static_cast<Combiner*>(ctx->combiner)->submit(ctx, r);
-        if (st != BBP_OK && !r.err.empty()) tls_error() = r.err;
+        if (st != BBP_OK) set_tls_error(ctx, !r.err.empty() ? r.err : st == BBP_ERR_VERIFY ? "proof rejected" : "malformed proof");
         return st;
-    });
+    }, ctx);
+}
+
+extern "C" int32_t bbp_verify_async(bbp_ctx* ctx, const uint8_t* record, uint32_t record_len, const uint8_t score[32],
+                                    const uint8_t z_img[32], const uint8_t seed[32], const uint8_t* pub_list, uint32_t N, bbp_done_fn done,
+                                    void* user) {
+    if (!ctx || !record || !score || !z_img || !seed || !done) return BBP_ERR_BAD_ARG;
+    int32_t rc = api_guard(ctx, [&]() -> int32_t { return check_n(ctx, N); });
+    if (rc) return rc;
+    if (!pub_list) return BBP_ERR_BAD_ARG;
+    uint8_t ver = 0;
+    if ((rc = screen_verify_args(record, record_len, score, z_img, seed, N, &ver))) return rc;  // decided on the host: no callback
+    return no_throw([&]() -> int32_t {
+        Request* r = new Request();
+        r->kind = 1;
+        r->N = N;
+        r->rec_ver = ver;
+        fill_verify_input(r->own_in, record, record_len, score, z_img, seed, pub_list, N);
+        r->in = r->own_in.data();
+        r->in_len = r->own_in.size();
+        r->on_done = async_done;
+        r->origin = ctx;
+        r->user_fn = done;
+        r->user = user;
+        if (!static_cast<Combiner*>(ctx->combiner)->submit_async(ctx, r)) {
+            delete r;
+            set_tls_error(ctx, "call combiner: cannot start a batch thread");
+            return BBP_ERR_INTERNAL;
+        }
+        return BBP_OK;
+    }, ctx);
 }
 
 extern "C" int32_t bbp_set_batching(bbp_ctx* ctx, uint32_t window_us, uint32_t max_batch) {
@@ -605,6 +723,11 @@ extern "C" int32_t bbp_set_batching(bbp_ctx* ctx, uint32_t window_us, uint32_t m
 extern "C" int32_t bbp_batching_stats(bbp_ctx* ctx, uint64_t* n_calls, uint64_t* n_requests, uint32_t* max_seen) {
     if (!ctx || !ctx->combiner) return BBP_ERR_BAD_ARG;
     return no_throw([&]() -> int32_t {
+        if (ctx->owner && ctx->owner->combiner) {  // a pool member: the batches its pool's combiner has dealt to it
+            static_cast<Combiner*>(ctx->owner->combiner)->target_stats(ctx->member_index, n_calls, n_requests);
+            if (max_seen) *max_seen = 0;
+            return BBP_OK;
+        }
         static_cast<Combiner*>(ctx->combiner)->stats(n_calls, n_requests, max_seen);
         return BBP_OK;
     });
@@ -612,6 +735,7 @@ extern "C" int32_t bbp_batching_stats(bbp_ctx* ctx, uint64_t* n_calls, uint64_t*
 
 extern "C" int32_t bbp_debug_challenges(bbp_ctx* ctx, uint32_t B, uint32_t N, uint32_t proof, uint8_t* out32x32) {
     if (!ctx || !out32x32 || proof >= B) return BBP_ERR_BAD_ARG;
+    if (is_pool(ctx)) return pool_reject(ctx, "bbp_debug_challenges");
     return api_guard(ctx, [&]() -> int32_t {
         BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
         BBP_HIP_TRY(ctx, hipDeviceSynchronize());
@@ -621,6 +745,7 @@ extern "C" int32_t bbp_debug_challenges(bbp_ctx* ctx, uint32_t B, uint32_t N, ui
 
 extern "C" int32_t bbp_set_profiling(bbp_ctx* ctx, int32_t on) {
     if (!ctx) return BBP_ERR_BAD_ARG;
+    if (is_pool(ctx)) return pool_reject(ctx, "bbp_set_profiling");
     return api_guard(ctx, [&]() -> int32_t {
         ctx->profile = on != 0;
         return BBP_OK;
@@ -630,6 +755,7 @@ extern "C" int32_t bbp_set_profiling(bbp_ctx* ctx, int32_t on) {
 // Drains the recorded events: out[2i] = kernel tag, out[2i+1] = microseconds. Synchronises the device.
 extern "C" int32_t bbp_last_timings(bbp_ctx* ctx, float* out, uint32_t cap, uint32_t* n) {
     if (!ctx || !n) return BBP_ERR_BAD_ARG;
+    if (is_pool(ctx)) return pool_reject(ctx, "bbp_last_timings");
     return api_guard(ctx, [&]() -> int32_t {
         BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
         BBP_HIP_TRY(ctx, hipDeviceSynchronize());

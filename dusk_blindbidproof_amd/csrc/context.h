@@ -74,6 +74,12 @@ struct bbp_ctx {
     // lock one by one: submit.hip coalesces them into one batch call (group commit).
     std::recursive_mutex mu;
     void* combiner = nullptr;  // bbp::Combiner* (submit.hip): coalesces concurrent bbp_prove / bbp_verify calls into batch calls
+    // Device pool (pool.cpp, bbp_pool_init / bbp_init_all): a context with `members` owns no device state of its own -- it is the
+    // handle the reference's prove() / verify() callers share when the node has several GPUs: ONE combiner deals their batches to
+    // the members (one ordinary context per GPU), the host-pointer batch calls block-split over them.  A member knows its pool.
+    std::vector<bbp_ctx*> members;
+    bbp_ctx* owner = nullptr;
+    uint32_t member_index = 0;
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;            // opening stage of the prover pipeline (prover.hip)
@@ -263,8 +269,23 @@ struct StreamGuard {
 inline hipStream_t pick_stream(bbp_ctx* ctx, void* stream) { return stream == BBP_STREAM_CONTEXT ? ctx->stream : (hipStream_t)stream; }
 
 // ---- the extern "C" barrier: lock + no exception ever crosses the boundary (include/bbp.h promises both) ---------------------
-// bbp_last_error reports per calling thread: a failing call copies the context's message into a thread-local slot under the lock.
+// bbp_last_error reports per calling thread AND per context: a failing call leaves (context, message) in a thread-local slot;
+// bbp_last_error(ctx) answers from the slot only if it belongs to ctx, otherwise with the context's own last message -- a thread
+// that drives several contexts (one per GPU) never reads one context's failure as another's.
 std::string& tls_error();
+const void*& tls_error_owner();
+inline void set_tls_error(const void* ctx, const std::string& msg) {
+    try {
+        tls_error() = msg;
+        tls_error_owner() = ctx;
+    } catch (...) {
+    }
+}
+inline const char* status_text(int32_t rc) {
+    static const char* const names[] = {"ok", "verification failed", "bid list needs more than 2048 multipliers", "malformed input", "invalid argument",
+                                        "device failure", "internal error"};
+    return rc >= 0 && rc <= 6 ? names[rc] : "unknown status";
+}
 int32_t fault_injected(const char* site);  // BBP_FAULT_INJECT=<site>: throw at that site (tests/test_capi_symbols.py)
 
 template <class F>
@@ -273,6 +294,7 @@ int32_t api_guard(bbp_ctx* ctx, F&& body) noexcept {
     try {
         std::lock_guard<std::recursive_mutex> lk(ctx->mu);
         try {
+            ctx->err.clear();  // whatever this call reports is this call's own message, never an older failure's
             rc = body();
         } catch (const std::invalid_argument& e) {
             ctx->err = std::string("invalid argument: ") + e.what();
@@ -289,7 +311,8 @@ int32_t api_guard(bbp_ctx* ctx, F&& body) noexcept {
         }
         if (rc != BBP_OK) {
             try {
-                tls_error() = ctx->err;
+                if (ctx->err.empty()) ctx->err = status_text(rc);  // a failure path that set no text still reports its own status
+                set_tls_error(ctx, ctx->err);
             } catch (...) {
             }
         }
@@ -298,6 +321,13 @@ int32_t api_guard(bbp_ctx* ctx, F&& body) noexcept {
     }
     return rc;
 }
+
+inline bool is_pool(const bbp_ctx* ctx) { return ctx && !ctx->members.empty(); }
+// pool.cpp: the host-pointer batch calls on a pool handle (block split by index over the members, results in request order)
+int32_t pool_prove_batch(bbp_ctx* pool, uint32_t B, uint32_t N, const uint8_t* in, const uint8_t* entropy, uint8_t* out, int32_t* status);
+int32_t pool_verify_batch(bbp_ctx* pool, uint32_t B, uint32_t N, const uint8_t* in, int32_t* status, bool aggregated, uint32_t group, uint32_t* n_fallback);
+int32_t pool_msm_batch(bbp_ctx* pool, uint32_t B, uint32_t n_terms, const uint8_t* scalars, uint32_t layout, uint8_t* out32);
+int32_t pool_reject(bbp_ctx* pool, const char* what);  // BBP_ERR_BAD_ARG + message: entry points that need ONE device
 
 // msm.hip
 // base_idx_dev holds n_idx_sets lists of n_terms indices; MSM number i uses list (i % n_idx_sets)

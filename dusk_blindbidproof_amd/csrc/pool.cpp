@@ -1,0 +1,209 @@
+// Device pool: ONE handle in front of one engine context per GPU (include/bbp.h "Device pool").
+//
+// The reference serves every connection on its own dusk-uds worker thread and each of them calls Proof::prove / Verify::verify
+// (src/main.rs:55, src/futures/main.rs:46-56, src/futures/prove.rs:21-26, verify.rs:21-26).  With the binding of INTEGRATION.md
+// those calls land in bbp_prove / bbp_verify on one shared handle; if that handle is a single context, one GPU of the node
+// works and seven idle.  A pool handle is a bbp_ctx without device state whose `members` are ordinary contexts:
+//   * bbp_prove / bbp_verify: ONE call combiner (submit.cpp) collects the concurrent callers and deals every batch to the member
+//     with the fewest combined calls in flight; a burst is split into fair shares over the idle members;
+//   * bbp_prove_batch / bbp_verify_batch[_aggregated] / bbp_msm_batch: contiguous block split by index over the members, sizes
+//     differing by at most one (= sharding.shard_range), one host thread per member, results land in request order
+//     because every member writes straight into its slice of the caller's buffers;
+//   * no data crosses between GPUs (proofs are independent units; tables are replicated per member at init).
+// Host-only C++ (no kernels); everything that touches a device goes through the members' own entry points.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "context.h"
+#include "submit.h"
+
+namespace bbp {
+
+int32_t pool_reject(bbp_ctx* pool, const char* what) {
+    try {
+        std::lock_guard<std::recursive_mutex> lk(pool->mu);
+        pool->err = std::string(what) + ": not available on a pool handle (device pointers and streams belong to ONE device: use bbp_pool_member)";
+        set_tls_error(pool, pool->err);
+    } catch (...) {
+    }
+    return BBP_ERR_BAD_ARG;
+}
+
+// [lo, hi) of member i when B items are block-split over n members: the same arithmetic as sharding.shard_range
+static void shard_range(uint32_t B, uint32_t i, uint32_t n, uint32_t* lo, uint32_t* hi) {
+    const uint32_t base = B / n, rem = B % n;
+    *lo = i * base + (i < rem ? i : rem);
+    *hi = *lo + base + (i < rem ? 1u : 0u);
+}
+
+// run body(member, lo, hi) for every member with a non-empty block, one thread each (the first block on the calling thread);
+// returns the first non-zero status in member order and leaves that member's message in this thread's bbp_last_error slot
+template <class F>
+static int32_t for_each_block(bbp_ctx* pool, uint32_t B, F&& body) {
+    const uint32_t n = (uint32_t)pool->members.size();
+    std::vector<int32_t> rc(n, BBP_OK);
+    std::vector<std::string> msg(n);
+    auto run = [&](uint32_t i) {
+        uint32_t lo, hi;
+        shard_range(B, i, n, &lo, &hi);
+        if (lo == hi) return;
+        try {
+            rc[i] = body(pool->members[i], lo, hi);
+            if (rc[i] != BBP_OK) msg[i] = bbp_last_error(pool->members[i]);  // this worker thread's slot
+        } catch (...) {
+            rc[i] = BBP_ERR_INTERNAL;
+            msg[i] = "internal error in a pool worker";
+        }
+    };
+    std::vector<uint32_t> active, inline_blocks;
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t lo, hi;
+        shard_range(B, i, n, &lo, &hi);
+        if (lo != hi) active.push_back(i);
+    }
+    std::vector<std::thread> th;
+    for (size_t k = 1; k < active.size(); k++) {
+        try {
+            th.emplace_back(run, active[k]);
+        } catch (...) {  // no thread to be had: that block runs on the calling thread after its own
+            inline_blocks.push_back(active[k]);
+        }
+    }
+    if (!active.empty()) run(active[0]);
+    for (uint32_t i : inline_blocks) run(i);
+    for (auto& t : th) t.join();
+    for (uint32_t i = 0; i < n; i++)
+        if (rc[i] != BBP_OK) {
+            try {
+                std::lock_guard<std::recursive_mutex> lk(pool->mu);
+                pool->err = "member " + std::to_string(i) + " (device " + std::to_string(pool->members[i]->device) + "): " + msg[i];
+                set_tls_error(pool, pool->err);
+            } catch (...) {
+            }
+            return rc[i];
+        }
+    return BBP_OK;
+}
+
+int32_t pool_prove_batch(bbp_ctx* pool, uint32_t B, uint32_t N, const uint8_t* in, const uint8_t* entropy, uint8_t* out, int32_t* status) {
+    const size_t in_stride = 7 * 32 + (size_t)N * 32 + 8, ent_stride = bbp_entropy_size(N), out_stride = bbp_proof_record_size(N);
+    return for_each_block(pool, B, [&](bbp_ctx* m, uint32_t lo, uint32_t hi) {
+        return bbp_prove_batch(m, hi - lo, N, in + in_stride * lo, entropy ? entropy + ent_stride * lo : nullptr, out + out_stride * lo, status + lo);
+    });
+}
+
+int32_t pool_verify_batch(bbp_ctx* pool, uint32_t B, uint32_t N, const uint8_t* in, int32_t* status, bool aggregated, uint32_t group,
+                          uint32_t* n_fallback) {
+    const size_t stride = (size_t)bbp_proof_record_size(N) + 96 + (size_t)N * 32;
+    std::vector<uint32_t> nfb(pool->members.size(), 0);
+    const int32_t rc = for_each_block(pool, B, [&](bbp_ctx* m, uint32_t lo, uint32_t hi) {
+        if (!aggregated) return bbp_verify_batch(m, hi - lo, N, in + stride * lo, status + lo);
+        return bbp_verify_batch_aggregated(m, hi - lo, N, in + stride * lo, status + lo, group, &nfb[m->member_index]);
+    });
+    if (n_fallback) {
+        *n_fallback = 0;
+        for (uint32_t v : nfb) *n_fallback += v;
+    }
+    return rc;
+}
+
+int32_t pool_msm_batch(bbp_ctx* pool, uint32_t B, uint32_t n_terms, const uint8_t* scalars, uint32_t layout, uint8_t* out32) {
+    return for_each_block(pool, B, [&](bbp_ctx* m, uint32_t lo, uint32_t hi) {
+        return bbp_msm_batch(m, hi - lo, n_terms, scalars + (size_t)32 * n_terms * lo, layout, out32 + (size_t)32 * lo);
+    });
+}
+
+}  // namespace bbp
+
+using namespace bbp;
+
+extern "C" int32_t bbp_pool_init(const int32_t* devices, uint32_t n_devices, bbp_ctx** out) {
+    if (!out) return BBP_ERR_BAD_ARG;
+    *out = nullptr;
+    if (!devices || n_devices == 0 || n_devices > 64) return BBP_ERR_BAD_ARG;
+    bbp_ctx* pool = nullptr;
+    try {
+        pool = new bbp_ctx();
+        pool->device = -1;
+        *out = pool;  // returned even on failure so that bbp_last_error works; the caller frees it
+        std::vector<bbp_ctx*> made(n_devices, nullptr);
+        std::vector<int32_t> rc(n_devices, BBP_OK);
+        std::vector<std::string> msg(n_devices);
+        // every member derives and uploads its own tables (~1 s each): all at once
+        auto one = [&](uint32_t i) {
+            rc[i] = bbp_init(devices[i], &made[i]);
+            if (rc[i] != BBP_OK) msg[i] = made[i] ? bbp_last_error(made[i]) : "no usable HIP device";
+        };
+        {
+            std::vector<std::thread> th;
+            std::vector<uint32_t> inline_members;
+            for (uint32_t i = 1; i < n_devices; i++) {
+                try {
+                    th.emplace_back(one, i);
+                } catch (...) {
+                    inline_members.push_back(i);
+                }
+            }
+            one(0);
+            for (uint32_t i : inline_members) one(i);
+            for (auto& t : th) t.join();
+        }
+        for (uint32_t i = 0; i < n_devices; i++)
+            if (rc[i] != BBP_OK) {
+                pool->err = "bbp_pool_init: member " + std::to_string(i) + " (device " + std::to_string(devices[i]) + "): " + msg[i];
+                set_tls_error(pool, pool->err);
+                for (bbp_ctx* m : made)
+                    if (m) bbp_free(m);
+                return rc[i];
+            }
+        for (uint32_t i = 0; i < n_devices; i++) {
+            made[i]->owner = pool;
+            made[i]->member_index = i;
+        }
+        pool->members = made;
+        Combiner* c = new Combiner();
+        pool->combiner = c;
+        c->set_targets(made);
+        if (const char* e = getenv("BBP_BATCH_WINDOW_US")) c->configure((uint32_t)atoi(e), 0);
+        const char* e = getenv("BBP_BATCH_STAGGER_US");
+        c->set_stagger(e ? (uint32_t)atoi(e) : 35000u);
+        return BBP_OK;
+    } catch (const std::exception& e) {
+        if (pool) pool->err = std::string("bbp_pool_init: ") + e.what();
+        return BBP_ERR_INTERNAL;
+    } catch (...) {
+        return BBP_ERR_INTERNAL;
+    }
+}
+
+extern "C" int32_t bbp_init_all(bbp_ctx** out) {
+    if (!out) return BBP_ERR_BAD_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        fprintf(stderr, "bbp_init_all: no usable HIP device (count=%d); this library has no CPU path\n", n);
+        return BBP_ERR_DEVICE;
+    }
+    std::vector<int32_t> devs;
+    for (int i = 0; i < n && i < 64; i++) devs.push_back(i);
+    return bbp_pool_init(devs.data(), (uint32_t)devs.size(), out);
+}
+
+extern "C" uint32_t bbp_pool_size(const bbp_ctx* ctx) { return ctx ? (uint32_t)ctx->members.size() : 0u; }
+
+extern "C" bbp_ctx* bbp_pool_member(bbp_ctx* ctx, uint32_t i) { return ctx && i < ctx->members.size() ? ctx->members[i] : nullptr; }
+
+extern "C" int32_t bbp_pool_member_stats(bbp_ctx* ctx, uint32_t i, uint64_t* n_calls, uint64_t* n_requests) {
+    if (!is_pool(ctx) || i >= ctx->members.size() || !ctx->combiner) return BBP_ERR_BAD_ARG;
+    try {
+        static_cast<Combiner*>(ctx->combiner)->target_stats(i, n_calls, n_requests);
+        return BBP_OK;
+    } catch (...) {
+        return BBP_ERR_INTERNAL;
+    }
+}

@@ -107,14 +107,22 @@ static int32_t init_body(int32_t device, bbp_ctx** out);
 extern "C" int32_t bbp_init(int32_t device, bbp_ctx** out) {
     if (!out) return BBP_ERR_BAD_ARG;
     *out = nullptr;
+    if (device == -1) return bbp_init_all(out);  // a pool over every visible GPU (pool.cpp)
     try {
         const int32_t rc = init_body(device, out);
-        if (rc != BBP_OK && *out) tls_error() = (*out)->err;
+        if (rc != BBP_OK && *out) set_tls_error(*out, (*out)->err);
         return rc;
     } catch (const std::exception& e) {
-        if (*out) (*out)->err = std::string("bbp_init: ") + e.what();
+        if (*out) {
+            (*out)->err = std::string("bbp_init: ") + e.what();
+            set_tls_error(*out, (*out)->err);
+        }
         return BBP_ERR_INTERNAL;
     } catch (...) {
+        if (*out) {
+            (*out)->err = "bbp_init: unknown exception";
+            set_tls_error(*out, (*out)->err);
+        }
         return BBP_ERR_INTERNAL;
     }
 }
@@ -231,6 +239,18 @@ static int32_t init_body(int32_t device, bbp_ctx** out) {
 
 extern "C" void bbp_free(bbp_ctx* ctx) {
     if (!ctx) return;
+    if (is_pool(ctx)) {  // a pool owns its members and its combiner, no device state
+        for (bbp_ctx* m : ctx->members) bbp_free(m);
+        ctx->members.clear();
+        delete static_cast<Combiner*>(ctx->combiner);
+        delete ctx;
+        return;
+    }
+    if (!ctx->stream && !ctx->gens && ctx->device < 0) {  // a pool whose initialisation failed before it had members
+        delete static_cast<Combiner*>(ctx->combiner);
+        delete ctx;
+        return;
+    }
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     void* ptrs[] = {ctx->gens, ctx->ptable, ctx->btab, ctx->slice_fold[0].p, ctx->slice_fold[1].p, ctx->slice_fold[2].p, ctx->slice_fold[3].p,
@@ -292,17 +312,18 @@ extern "C" void bbp_free(bbp_ctx* ctx) {
 extern "C" const char* bbp_last_error(const bbp_ctx* ctx) {
     if (!ctx) return "null context";
     try {
-        std::string& t = tls_error();
-        if (t.empty()) {
-            std::lock_guard<std::recursive_mutex> lk(const_cast<bbp_ctx*>(ctx)->mu);
-            t = ctx->err;
-        }
-        return t.c_str();
+        if (tls_error_owner() == ctx) return tls_error().c_str();  // this thread's last failure on THIS handle
+        // this thread has not failed on this handle: the handle's own last message, through a buffer that leaves the slot alone
+        static thread_local std::string other;
+        std::lock_guard<std::recursive_mutex> lk(const_cast<bbp_ctx*>(ctx)->mu);
+        other = ctx->err;
+        return other.c_str();
     } catch (...) {
         return "error text unavailable";
     }
 }
 
+// (a pool handle has no streams: nullptr)
 extern "C" void* bbp_context_stream(bbp_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 extern "C" void* bbp_context_copy_stream(bbp_ctx* ctx) { return ctx ? (void*)ctx->copy : nullptr; }
 extern "C" void* bbp_context_verify_stream(bbp_ctx* ctx, uint32_t lane) { return ctx && lane < bbp_ctx::VLANES ? (void*)ctx->vl[lane].stream : nullptr; }
@@ -312,6 +333,16 @@ extern "C" void* bbp_context_verify_stream(bbp_ctx* ctx, uint32_t lane) { return
 // state cannot fault the GPU, this word so that it cannot pass silently).
 extern "C" int32_t bbp_check_health(bbp_ctx* ctx, uint32_t* flags) {
     if (!ctx || !flags) return BBP_ERR_BAD_ARG;
+    if (is_pool(ctx)) {  // the members' words OR-ed
+        *flags = 0;
+        for (bbp_ctx* m : ctx->members) {
+            uint32_t f = 0;
+            const int32_t rc = bbp_check_health(m, &f);
+            if (rc) return rc;
+            *flags |= f;
+        }
+        return BBP_OK;
+    }
     return api_guard(ctx, [&]() -> int32_t {
         BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
         BBP_HIP_TRY(ctx, hipDeviceSynchronize());
@@ -322,6 +353,7 @@ extern "C" int32_t bbp_check_health(bbp_ctx* ctx, uint32_t* flags) {
 
 extern "C" int32_t bbp_get_generator(bbp_ctx* ctx, uint32_t index, uint8_t out32[32]) {
     if (!ctx || index >= BBP_NUM_BASES) return BBP_ERR_BAD_ARG;
+    if (is_pool(ctx)) return bbp_get_generator(ctx->members[0], index, out32);  // every member holds the same tables
     return api_guard(ctx, [&]() -> int32_t {
         BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
         int32_t rc = dev_reserve(ctx, ctx->enc, 32);
@@ -338,6 +370,7 @@ extern "C" int32_t bbp_get_generator(bbp_ctx* ctx, uint32_t index, uint8_t out32
 
 extern "C" int32_t bbp_get_mimc_constant(bbp_ctx* ctx, uint32_t i, uint8_t out32[32]) {
     if (!ctx || i >= BBP_MIMC_ROUNDS) return BBP_ERR_BAD_ARG;
+    if (is_pool(ctx)) return bbp_get_mimc_constant(ctx->members[0], i, out32);
     return api_guard(ctx, [&]() -> int32_t {
         BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
         BBP_HIP_TRY(ctx, hipMemcpy(out32, ctx->mimc_c + i, 32, hipMemcpyDeviceToHost));  // read back from the device copy

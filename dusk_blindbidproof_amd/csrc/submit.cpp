@@ -4,6 +4,7 @@
 
 #include <string.h>
 
+#include <algorithm>
 #include <chrono>
 
 namespace bbp {
@@ -42,63 +43,128 @@ static bool same_class(const Request* a, const Request* b) {
     return a->kind == b->kind && a->N == b->N && a->rec_ver == b->rec_ver && a->in_len == b->in_len && (a->entropy == nullptr) == (b->entropy == nullptr);
 }
 
-void Combiner::designate_locked() {
-    for (Request* q : q_) {
-        if (leaders_ >= MAX_LEADERS) return;
-        if (!q->lead && !q->leading) {  // a leader in its window still has its own request queued: never designate it twice
-            q->lead = true;
-            leaders_++;
-            q->cv.notify_one();
+void Combiner::set_targets(const std::vector<bbp_ctx*>& targets) {
+    std::lock_guard<std::mutex> lk(mu_);
+    targets_.clear();
+    for (bbp_ctx* c : targets) {
+        Target t;
+        t.ctx = c;
+        targets_.push_back(t);
+    }
+}
+
+void Combiner::target_stats(size_t i, uint64_t* n_calls, uint64_t* n_requests) {
+    std::lock_guard<std::mutex> lk(mu_);
+    if (n_calls) *n_calls = i < targets_.size() ? targets_[i].n_calls : 0;
+    if (n_requests) *n_requests = i < targets_.size() ? targets_[i].n_requests : 0;
+}
+
+// least-loaded target; ties go round-robin so that an idle pool is used evenly
+size_t Combiner::pick_target_locked() {
+    size_t best = 0;
+    int best_load = 1 << 30;
+    for (size_t k = 0; k < targets_.size(); k++) {
+        const size_t i = (rr_ + k) % targets_.size();
+        if (targets_[i].running < best_load) {
+            best_load = targets_[i].running;
+            best = i;
         }
     }
+    rr_ = (best + 1) % targets_.size();
+    return best;
+}
+
+Combiner::~Combiner() {
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        stop_ = true;
+    }
+    cv_work_.notify_all();
+    cv_window_.notify_all();
+    for (auto& t : threads_) t.join();
+}
+
+// queue a request; start the batch threads with the first one (two per target: a second batch is prepared and its opening stage
+// runs while the first is on the device).  false = no thread could be started and none is running
+bool Combiner::enqueue_locked(bbp_ctx* ctx, Request* r) {
+    if (targets_.empty()) {  // a plain context: its one target is itself
+        Target t;
+        t.ctx = ctx;
+        targets_.push_back(t);
+    }
+    while ((int)threads_.size() < max_leaders_locked()) {
+        try {
+            threads_.emplace_back([this] { thread_main(); });
+        } catch (...) {
+            break;
+        }
+    }
+    if (threads_.empty()) return false;
+    q_.push_back(r);
+    if (idle_ > 0) cv_work_.notify_one();
+    if (q_.size() >= max_batch_) cv_window_.notify_all();  // a thread in its window / holding back has a full batch now
+    return true;
 }
 
 int32_t Combiner::submit(bbp_ctx* ctx, Request& r) {
     std::unique_lock<std::mutex> lk(mu_);
-    q_.push_back(&r);
-    designate_locked();
-    cv_window_.notify_one();  // a leader sitting in its batching window counts arrivals
-    auto resign = [&] {       // give the leader slot back and let a queued caller have it
-        r.leading = false;
-        leaders_--;
-        designate_locked();
-    };
+    r.on_done = nullptr;
+    if (!enqueue_locked(ctx, &r)) {
+        r.err = "call combiner: cannot start a batch thread";
+        return r.status = 6;
+    }
+    r.cv.wait(lk, [&] { return r.done; });
+    return r.status;
+}
+
+bool Combiner::submit_async(bbp_ctx* ctx, Request* r) {
+    std::lock_guard<std::mutex> lk(mu_);
+    return enqueue_locked(ctx, r);
+}
+
+void Combiner::thread_main() {
+    std::unique_lock<std::mutex> lk(mu_);
     for (;;) {
-        r.cv.wait(lk, [&] { return r.done || r.lead; });
-        if (!r.lead) return r.status;  // done, and not holding a leader slot
-        r.lead = false;
-        r.leading = true;
-        if (r.done || q_.empty()) {  // nothing (left) for this leader to run
-            resign();
-            if (r.done) return r.status;
-            continue;  // r is inside another leader's batch: wait for it
-        }
+        idle_++;
+        cv_work_.wait(lk, [&] { return stop_ || !q_.empty(); });
+        idle_--;
+        if (stop_) return;
         // Optional window: give concurrent callers a moment to join this batch.
         if (window_us_) {
             const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(window_us_);
-            while (q_.size() < max_batch_ && wait_until_steady(cv_window_, lk, deadline) != std::cv_status::timeout) {
+            while (!stop_ && q_.size() < max_batch_ && wait_until_steady(cv_window_, lk, deadline) != std::cv_status::timeout) {
             }
-            if (q_.empty()) {  // the other leader took everything meanwhile
-                resign();
-                if (r.done) return r.status;
-                continue;
-            }
+            if (stop_) return;
+            if (q_.empty()) continue;  // another thread took everything meanwhile
         }
-        if (stagger_us_ && inflight_ > 0 && q_.front()->kind == 0) {  // a PROVE batch is on the device and this would be another:
+        // reserve the least-loaded target now (under the lock), so that two threads never count on the same idle device
+        const size_t ti = pick_target_locked();
+        size_t idle_targets = 0;  // targets with nothing reserved, this one included if so: what a burst should spread over
+        for (const Target& t : targets_) idle_targets += t.running == 0;
+        targets_[ti].running++;
+        if (stagger_us_ && targets_[ti].prove_inflight > 0 && q_.front()->kind == 0) {  // a PROVE batch is on that device and this would be another:
             // let it grow until that one's opening stage is over (verifications have no such stage and never wait here)
-            const auto start_at = last_start_ + std::chrono::microseconds(stagger_us_);
-            while (inflight_ > 0 && q_.size() < max_batch_ && wait_until_steady(cv_window_, lk, start_at) != std::cv_status::timeout) {
+            const auto start_at = targets_[ti].last_start + std::chrono::microseconds(stagger_us_);
+            while (!stop_ && targets_[ti].prove_inflight > 0 && q_.size() < max_batch_ && wait_until_steady(cv_window_, lk, start_at) != std::cv_status::timeout) {
             }
-            if (q_.empty()) {
-                resign();
-                if (r.done) return r.status;
+            if (stop_ || q_.empty()) {
+                targets_[ti].running--;
+                if (stop_) return;
                 continue;
             }
         }
-        // one batch from the head of the queue: everything of the head's class, in arrival order (r itself is usually in it)
+        // one batch from the head of the queue: requests of the head's class, in arrival order.  With several targets a thread
+        // takes its fair share only -- what is queued divided by the idle targets -- so the rest is there for the threads beside it.
         const Request* head = q_.front();
+        size_t limit = max_batch_;
+        if (targets_.size() > 1 && idle_targets > 1) {
+            size_t n_class = 0;
+            for (const Request* q : q_) n_class += same_class(q, head);
+            const size_t share = (n_class + idle_targets - 1) / idle_targets;
+            limit = std::min<size_t>(limit, std::max<size_t>(share, MIN_SHARE));
+        }
         std::vector<Request*> batch;
-        for (auto it = q_.begin(); it != q_.end() && batch.size() < max_batch_;) {
+        for (auto it = q_.begin(); it != q_.end() && batch.size() < limit;) {
             if (same_class(*it, head)) {
                 batch.push_back(*it);
                 it = q_.erase(it);
@@ -106,31 +172,38 @@ int32_t Combiner::submit(bbp_ctx* ctx, Request& r) {
                 ++it;
             }
         }
-        for (Request* b : batch)
-            if (b->lead) {  // designated but not yet awake, and now inside this batch: it will find nothing to lead
-                b->lead = false;
-                leaders_--;
-            }
-        const bool proving = batch[0]->kind == 0;  // inflight_ / last_start_ track prove batches only
+        if (!q_.empty() && idle_ > 0) cv_work_.notify_one();  // another class, or the rest of a burst: not this thread's batch
+        const bool proving = batch[0]->kind == 0;  // prove_inflight / last_start track prove batches only
         if (proving) {
-            inflight_++;
-            last_start_ = std::chrono::steady_clock::now();
+            targets_[ti].prove_inflight++;
+            targets_[ti].last_start = std::chrono::steady_clock::now();
         }
+        bbp_ctx* const where = targets_[ti].ctx;
         lk.unlock();
-        run_batch(ctx, batch);
+        run_batch(where, batch);
         lk.lock();
-        if (proving) inflight_--;
-        cv_window_.notify_all();  // a leader holding back behind this batch may go now
+        if (proving) targets_[ti].prove_inflight--;
+        targets_[ti].running--;
+        cv_window_.notify_all();  // a thread holding back behind this batch may go now
         n_calls_++;
         n_requests_ += batch.size();
+        targets_[ti].n_calls++;
+        targets_[ti].n_requests += batch.size();
         if (batch.size() > max_seen_) max_seen_ = (uint32_t)batch.size();
+        std::vector<Request*> hooks;
         for (Request* b : batch) {
-            b->done = true;
-            if (b != &r) b->cv.notify_one();
+            if (b->on_done) {
+                hooks.push_back(b);
+            } else {
+                b->done = true;
+                b->cv.notify_one();  // (the waiter cannot return, and its Request cannot die, before this thread lets go of mu_)
+            }
         }
-        resign();  // nobody serves other callers for longer than one batch
-        if (r.done && !r.lead) return r.status;
-        // (r.lead again: resign() found r still queued -- a different class than the batch it just ran -- and picked it)
+        if (!hooks.empty()) {  // asynchronous requests: completion hooks run with no lock held; each owns its Request from here on
+            lk.unlock();
+            for (Request* b : hooks) b->on_done(b);
+            lk.lock();
+        }
     }
 }
 

@@ -6,9 +6,13 @@
 // queue: the first caller to find the engine free becomes the leader, takes every queued request of its class (same kind, list
 // length, record layout, entropy mode), runs ONE bbp_prove_batch / bbp_verify_batch under the context lock and distributes the
 // results; requests that arrive while a batch is on the device form the next batch.  Up to TWO batches are in flight at a time
-// (two leaders): the host-pointer batch calls hold the context lock only while they enqueue, so the second batch's host work and
+// per device: the host-pointer batch calls hold the context lock only while they enqueue, so the second batch's host work and
 // its opening stage on the device run under the first batch's MSM stage -- the engine's cross-call pipeline, kept full by the
-// queue.  A leader runs ONE batch taken from the head of the queue, then leadership goes to a waiting caller.
+// queue.
+// Round 3: the batches are run by the combiner's OWN threads (two per target, started with the first request) instead of by
+// whichever caller found a free leader slot.  That is what makes the asynchronous entry points possible (bbp_prove_async /
+// bbp_verify_async: a request is queued and a callback fires when its batch is done -- what an epoll server or a Rust Future
+// needs, since it cannot park a thread per request); the blocking bbp_prove / bbp_verify are the same path plus a wait.
 #pragma once
 #include <stdint.h>
 
@@ -17,6 +21,7 @@
 #include <deque>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 struct bbp_ctx;
@@ -34,9 +39,14 @@ struct Request {
     int32_t status = 6;              // BBP_ERR_INTERNAL until the batch has run
     std::string err;
     bool done = false;
-    bool lead = false;     // designated to run a batch, not yet acknowledged
-    bool leading = false;  // acting as a leader right now (its own request may still sit in the queue during the window)
-    std::condition_variable cv;      // each waiter has its own: a finished batch wakes its members, not every queued caller
+    std::condition_variable cv;      // blocking callers: each waiter has its own, a finished batch wakes its members only
+    // asynchronous requests: called exactly once, on a combiner thread, with no lock held, after status / err / out are final;
+    // the hook owns the Request from then on (it may delete it).  nullptr = a blocking caller waits on cv instead.
+    void (*on_done)(Request*) = nullptr;
+    void (*user_fn)(void*, int32_t) = nullptr;  // what the C ABI's hook forwards to
+    void* user = nullptr;
+    const void* origin = nullptr;  // the handle the request was made on (a pool or a context): whose error slot the message belongs to
+    std::vector<uint8_t> own_in, own_entropy;  // storage of an asynchronous request's inputs (in / entropy point into them)
 };
 
 // what a combined call runs (capi_prove.hip); both take the context lock themselves
@@ -46,7 +56,22 @@ int32_t verify_batch_locked(bbp_ctx* ctx, uint32_t B, uint32_t N, uint32_t rec_v
 
 class Combiner {
   public:
+    // `ctx` is where the batch runs unless the combiner has been given targets (a device pool): then every batch goes to the
+    // least-loaded target
     int32_t submit(bbp_ctx* ctx, Request& r);
+    // queue and return: r->on_done fires when the batch that carried it is done.  false = the combiner has no thread to run it
+    // (thread creation failed): nothing was queued, the hook will not fire
+    bool submit_async(bbp_ctx* ctx, Request* r);
+    Combiner() = default;
+    ~Combiner();  // stops and joins the threads; no request may be outstanding (bbp_free must not race with calls)
+    Combiner(const Combiner&) = delete;
+    Combiner& operator=(const Combiner&) = delete;
+    // Device pool (pool.cpp): one combiner in front of several contexts (one per GPU).  A leader reserves the target with the
+    // fewest combined calls in flight, takes its fair share of what is queued (queue / idle targets, so that a burst spreads over
+    // the idle devices instead of landing on one) and runs it there; up to two batches per target are in flight, and the prover's
+    // stagger is kept per target.
+    void set_targets(const std::vector<bbp_ctx*>& targets);
+    void target_stats(size_t i, uint64_t* n_calls, uint64_t* n_requests);
     void configure(uint32_t window_us, uint32_t max_batch);
     // A leader that finds another batch in flight does not start before `us` after that batch STARTED: for the prover this is
     // the length of the opening stage (the next batch's opening cannot begin earlier anyway), and meanwhile the batch grows --
@@ -56,16 +81,30 @@ class Combiner {
 
   private:
     void run_batch(bbp_ctx* ctx, std::vector<Request*>& batch);
+    struct Target {
+        bbp_ctx* ctx = nullptr;
+        int running = 0;         // combined calls reserved / running on this target (any kind)
+        int prove_inflight = 0;  // prove batches among them
+        std::chrono::steady_clock::time_point last_start{};  // start of the last prove batch (stagger)
+        uint64_t n_calls = 0, n_requests = 0;
+    };
+    std::vector<Target> targets_;  // empty until the first submit of a plain context (then: that context)
+    size_t rr_ = 0;                // tie-break cursor
+    size_t pick_target_locked();
+    static constexpr uint32_t MIN_SHARE = 64;  // a fair share is never cut below this many requests: tiny batches pay the full latency floor
     std::mutex mu_;
-    std::condition_variable cv_window_;  // arrivals -> the leader that sits in its batching window
+    std::condition_variable cv_window_;  // arrivals -> a batch thread that sits in its batching window / holds back behind a prove batch
+    std::condition_variable cv_work_;    // arrivals -> an idle batch thread
     std::deque<Request*> q_;
-    static constexpr int MAX_LEADERS = 2;  // three (as many as there are staging slots) fragments closed-loop load into more, smaller batches:
-                                           // measured through the UDS server 14.7 k -> 11.5 k proofs/s prove-only, 8.2 k -> 7.1 k ops/s at 2048 connections
-    int leaders_ = 0;         // callers currently designated to run (or running) a batch
-    void designate_locked();  // hand free leader slots to queued callers
+    std::vector<std::thread> threads_;
+    int idle_ = 0;       // batch threads waiting for work
+    bool stop_ = false;
+    bool enqueue_locked(bbp_ctx* ctx, Request* r);
+    void thread_main();
+    static constexpr int LEADERS_PER_TARGET = 2;  // three (as many as there are staging slots) fragments closed-loop load into more, smaller batches:
+                                                  // measured through the UDS server 14.7 k -> 11.5 k proofs/s prove-only, 8.2 k -> 7.1 k ops/s at 2048 connections
+    int max_leaders_locked() const { return LEADERS_PER_TARGET * (int)(targets_.empty() ? 1 : targets_.size()); }
     uint32_t window_us_ = 0, max_batch_ = 4096, stagger_us_ = 0;
-    int inflight_ = 0;
-    std::chrono::steady_clock::time_point last_start_{};
     uint64_t n_calls_ = 0, n_requests_ = 0;
     uint32_t max_seen_ = 0;
 };

@@ -96,6 +96,7 @@ using namespace bbp;
 // Runs `blocks` x 256 lanes x `iters` iterations; *ops_per_sec = operations/s (ops per iteration per lane: 4,2,2,1,2,1).
 extern "C" int32_t bbp_ubench(bbp_ctx* ctx, int32_t kind, uint32_t blocks, uint32_t iters, double* ops_per_sec) {
     if (!ctx || !ops_per_sec || kind < 0 || kind > 5 || blocks == 0) return BBP_ERR_BAD_ARG;
+    if (is_pool(ctx)) return bbp_ubench(ctx->members[0], kind, blocks, iters, ops_per_sec);
     return api_guard(ctx, [&]() -> int32_t {
     BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
     BBP_HIP_TRY(ctx, hipDeviceSynchronize());  // ctx->vl[0].misc is the verifier's scratch: nothing of this context may still be using it

@@ -16,6 +16,10 @@
  * into batch calls on the device (group commit: whatever queued up while the previous batch ran goes out as the next batch), so
  * N concurrent single proofs cost about one batch of N, not N times one.  bbp_last_error is per calling thread.
  * bbp_free must not race with other calls on the same context.
+ *
+ * Several GPUs: bbp_init_all / bbp_pool_init return a POOL handle -- one context per GPU behind the same bbp_ctx* type -- that the
+ * host-pointer entry points accept like a context: the reference's worker threads keep calling bbp_prove / bbp_verify on ONE
+ * shared handle and every GPU of the node works (see "Device pool" below).
  */
 #ifndef BBP_H
 #define BBP_H
@@ -55,8 +59,38 @@ typedef enum {
 
 /* Replaces generate_cs_transcript()'s per-call generator derivation (src/blindbid/mod.rs:34-40) and the
  * lazy_static CONSTANTS (src/blindbid/mod.rs:7-24): derives them ONCE on `device` and keeps them resident.
- * `device` is a HIP device ordinal (one context per GPU / per rank). */
+ * `device` is a HIP device ordinal (one context per GPU / per rank); -1 = a pool over every visible GPU (bbp_init_all below). */
 int32_t bbp_init(int32_t device, bbp_ctx** out);
+
+/* ---- Device pool -----------------------------------------------------------------------------------------------------------------
+ * The reference's concurrency model is "one Proof::prove / Verify::verify per worker thread, all threads share the process-wide
+ * state" (src/main.rs:55, src/futures/main.rs:46-56).  On a node with several GPUs that shared state is a pool: ONE handle, one
+ * ordinary context per GPU behind it (tables replicated per GPU, no data ever crosses between GPUs -- proofs are independent).
+ *   bbp_init_all            one member per visible HIP device (every one must be gfx950); bbp_init(-1, &h) is the same call
+ *   bbp_pool_init           an explicit device list; a device may be named more than once (two members on one card: tests, or two
+ *                           engine pipelines per GPU)
+ * What a pool handle accepts:
+ *   bbp_prove / bbp_verify  ONE call combiner for the whole pool: concurrent callers are coalesced into device batches as on a
+ *                           single context, and every batch goes to the member with the fewest batches in flight; a burst is cut
+ *                           into fair shares over the idle members
+ *   bbp_prove_batch / bbp_verify_batch / bbp_verify_batch_aggregated / bbp_msm_batch
+ *                           contiguous block split by index over the members (block sizes differ by at most one: member i of n
+ *                           gets [i*B/n ...), the split of SURVEY.md 8e), one host thread per member, outputs and per-item
+ *                           statuses in request order; the call returns the first member's non-zero status, if any
+ *   bbp_witness_batch, bbp_get_generator, bbp_get_mimc_constant, bbp_ubench   served by member 0
+ *   bbp_check_health        the members' flags OR-ed;  bbp_set_batching / bbp_batching_stats: the pool's combiner
+ *   bbp_free                frees the members too
+ * What it refuses (BBP_ERR_BAD_ARG; device pointers and streams belong to one device -- take a member with bbp_pool_member and
+ * call it directly): every *_dev entry point, bbp_debug_challenges, bbp_set_profiling / bbp_last_timings; the stream getters
+ * return NULL. */
+int32_t bbp_init_all(bbp_ctx** out);
+int32_t bbp_pool_init(const int32_t* devices, uint32_t n_devices, bbp_ctx** out);
+uint32_t bbp_pool_size(const bbp_ctx* ctx);               /* number of members; 0 for an ordinary context */
+bbp_ctx* bbp_pool_member(bbp_ctx* ctx, uint32_t i);        /* borrowed: owned and freed by the pool */
+/* combined bbp_prove / bbp_verify device calls the pool has dealt to member i, and the requests they carried
+ * (bbp_batching_stats on the member handle reports the same pair) */
+int32_t bbp_pool_member_stats(bbp_ctx* ctx, uint32_t i, uint64_t* n_calls, uint64_t* n_requests);
+
 /* `stream` arguments of the _dev entry points: a hipStream_t of the caller -- NULL is the legacy default stream and is honoured
  * as such -- or BBP_STREAM_CONTEXT for the context's own (non-blocking) stream. */
 #define BBP_STREAM_CONTEXT ((void*)(intptr_t)-1)
@@ -125,6 +159,20 @@ uint32_t bbp_entropy_size(uint32_t N);      /* 32*(4+N) + 32 */
 /* Replaces Verify::new(..).verify() (src/blindbid/verify.rs:27-89). record layout as produced by bbp_prove. */
 int32_t bbp_verify(bbp_ctx* ctx, const uint8_t* record, uint32_t record_len, const uint8_t score[32],
                    const uint8_t z_img[32], const uint8_t seed[32], const uint8_t* pub_list, uint32_t N);
+
+/* Asynchronous forms of the two calls above, for hosts that cannot park a thread per request (an epoll server; a Rust Future --
+ * the reference's ProveFuture / VerifyFuture, src/futures/prove.rs:21-26, verify.rs:21-26, can store its Waker in `user` and be
+ * woken by `done`).  Same arguments, same screening, same combining into device batches.  Return value: BBP_OK = queued, and
+ * `done(user, status)` will be called exactly once, on an engine thread, with the status bbp_prove / bbp_verify would have
+ * returned; anything else = decided at once (bad arguments, a record that fails the structural parse), `done` is NOT called.
+ * The inputs are copied before the call returns; proof_out must stay valid until `done` runs (it is written before).  Inside
+ * the callback bbp_last_error(ctx) is the request's message.  `done` runs on a thread that every request of the next batch is
+ * waiting for: hand the result over and return (no blocking, no engine calls on the same context from inside it). */
+typedef void (*bbp_done_fn)(void* user, int32_t status);
+int32_t bbp_prove_async(bbp_ctx* ctx, const uint8_t scalars7[7 * 32], const uint8_t* pub_list, uint32_t N, uint64_t toggle,
+                        const uint8_t* entropy, uint8_t* proof_out, bbp_done_fn done, void* user);
+int32_t bbp_verify_async(bbp_ctx* ctx, const uint8_t* record, uint32_t record_len, const uint8_t score[32], const uint8_t z_img[32],
+                         const uint8_t seed[32], const uint8_t* pub_list, uint32_t N, bbp_done_fn done, void* user);
 
 /* The data-parallel path: B independent proofs with a common list length N, fixed-stride records.
  * in:  B * (7*32 + N*32 + 8) bytes: scalars7 || pub_list || toggle(u64 LE)

@@ -1,5 +1,6 @@
 // TEST INFRASTRUCTURE: the call combiner (dusk_blindbidproof_amd/csrc/submit.cpp, the product's own code) under ThreadSanitizer.
-// 48 threads submit prove / verify requests of three classes through one Combiner; the "engine" behind it is a stand-in that
+// 48 threads submit prove / verify requests of three classes through one Combiner -- once in front of one engine, once in front
+// of three (a device pool: batches dealt to the least-loaded target); the "engine" behind it is a stand-in that
 // checks batch consistency (one class per batch, max_batch respected, never more than two batches inside at once), sleeps a
 // little and answers with a function of the request.  Exit code 0 = every answer right, invariants held, no data race reported.
 #include <stdio.h>
@@ -46,11 +47,18 @@ int32_t verify_batch_locked(bbp_ctx* c, uint32_t B, uint32_t N, uint32_t, const 
 }
 }  // namespace bbp
 
-int main() {
-    bbp_ctx ctx;
+// one scenario: `n_targets` stand-in engines behind ONE combiner (n_targets == 1: a plain context, the target is whatever submit is
+// handed; more: a device pool -- set_targets)
+static int scenario(int n_targets) {
+    std::vector<bbp_ctx> ctxs(n_targets);
     bbp::Combiner comb;
-    comb.configure(100, ctx.max_batch);
+    comb.configure(100, ctxs[0].max_batch);
     comb.set_stagger(500);
+    if (n_targets > 1) {
+        std::vector<bbp_ctx*> t;
+        for (auto& c : ctxs) t.push_back(&c);
+        comb.set_targets(t);
+    }
     std::atomic<int> wrong{0};
     std::vector<std::thread> th;
     for (int t = 0; t < 48; t++)
@@ -71,7 +79,7 @@ int main() {
                 r.N = N;
                 r.in = in.data();
                 r.in_len = in.size();
-                const int32_t st = comb.submit(&ctx, r);
+                const int32_t st = comb.submit(&ctxs[0], r);
                 if (r.kind == 0 ? (st != 0 || out[0] != tag || out[out.size() - 1] != tag) : st != (tag & 1)) wrong++;
             }
         });
@@ -79,7 +87,20 @@ int main() {
     uint64_t calls = 0, reqs = 0;
     uint32_t biggest = 0;
     comb.stats(&calls, &reqs, &biggest);
-    printf("requests %llu in %llu combined calls, largest %u, max concurrent %d, wrong %d, bad batches %d\n", (unsigned long long)reqs,
-           (unsigned long long)calls, biggest, ctx.max_inside.load(), wrong.load(), ctx.bad.load());
-    return (wrong.load() || ctx.bad.load() || reqs != 48 * 40 || ctx.max_inside.load() > 2 || biggest > ctx.max_batch) ? 1 : 0;
+    int max_inside = 0, bad = 0, idle_targets = 0;
+    uint64_t per_target_sum = 0;
+    for (int i = 0; i < n_targets; i++) {
+        if (ctxs[i].max_inside.load() > max_inside) max_inside = ctxs[i].max_inside.load();
+        bad += ctxs[i].bad.load();
+        uint64_t c = 0, q = 0;
+        comb.target_stats((size_t)i, &c, &q);
+        per_target_sum += q;
+        idle_targets += c == 0;
+    }
+    printf("targets %d: requests %llu in %llu combined calls, largest %u, max concurrent per target %d, wrong %d, bad batches %d, unused targets %d\n",
+           n_targets, (unsigned long long)reqs, (unsigned long long)calls, biggest, max_inside, wrong.load(), bad, idle_targets);
+    // per target never more than two batches inside at once; every target of a pool gets work; the per-target counters add up
+    return (wrong.load() || bad || reqs != 48 * 40 || per_target_sum != reqs || max_inside > 2 || biggest > ctxs[0].max_batch || idle_targets) ? 1 : 0;
 }
+
+int main() { return scenario(1) | scenario(3); }

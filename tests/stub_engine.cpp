@@ -7,12 +7,14 @@
 
 #include <atomic>
 #include <string>
+#include <vector>
 
 #include "../dusk_blindbidproof_amd/csrc/submit.h"
 #include "../include/bbp.h"
 
 struct bbp_ctx {
     bbp::Combiner combiner;
+    std::vector<bbp_ctx*> members;  // a stub pool: fake member contexts behind this handle's combiner (bbp_pool_init)
     std::atomic<uint64_t> batch_calls{0};
     std::atomic<int> inside{0}, max_inside{0};  // combined calls running at the same time (the combiner allows two)
 };
@@ -83,7 +85,26 @@ int32_t bbp_init(int32_t, bbp_ctx** out) {
     *out = new bbp_ctx();
     return BBP_OK;
 }
-void bbp_free(bbp_ctx* c) { delete c; }
+void bbp_free(bbp_ctx* c) {
+    if (!c) return;
+    std::vector<bbp_ctx*> members = c->members;
+    delete c;  // joins the combiner's threads first: nothing runs on a member afterwards
+    for (bbp_ctx* m : members) delete m;
+}
+int32_t bbp_pool_init(const int32_t* devices, uint32_t n, bbp_ctx** out) {
+    if (!devices || !n || !out) return BBP_ERR_BAD_ARG;
+    bbp_ctx* p = new bbp_ctx();
+    for (uint32_t i = 0; i < n; i++) p->members.push_back(new bbp_ctx());
+    p->combiner.set_targets(p->members);
+    *out = p;
+    return BBP_OK;
+}
+uint32_t bbp_pool_size(const bbp_ctx* c) { return c ? (uint32_t)c->members.size() : 0; }
+int32_t bbp_pool_member_stats(bbp_ctx* c, uint32_t i, uint64_t* calls, uint64_t* reqs) {
+    if (!c || i >= c->members.size()) return BBP_ERR_BAD_ARG;
+    c->combiner.target_stats(i, calls, reqs);
+    return BBP_OK;
+}
 const char* bbp_last_error(const bbp_ctx*) { return t_err.c_str(); }
 uint32_t bbp_proof_record_size(uint32_t N) { return 1121 + 32 * (4 + N); }
 int32_t bbp_set_batching(bbp_ctx* c, uint32_t w, uint32_t m) {
@@ -94,7 +115,16 @@ int32_t bbp_batching_stats(bbp_ctx* c, uint64_t* a, uint64_t* b, uint32_t* m) {
     c->combiner.stats(a, b, m);
     return BBP_OK;
 }
-int32_t stub_max_concurrency(bbp_ctx* c) { return c->max_inside.load(); }
+int32_t bbp_check_health(bbp_ctx*, uint32_t* flags) {
+    if (flags) *flags = 0;
+    return BBP_OK;
+}
+int32_t stub_max_concurrency(bbp_ctx* c) {  // per device: the largest number of combined calls any one (member) context saw at once
+    int m = c->max_inside.load();
+    for (bbp_ctx* x : c->members)
+        if (x->max_inside.load() > m) m = x->max_inside.load();
+    return m;
+}
 int32_t bbp_prove(bbp_ctx* c, const uint8_t s7[7 * 32], const uint8_t* pub, uint32_t N, uint64_t toggle, const uint8_t* ent, uint8_t* out,
                   uint32_t* plen) {
     if (N == 0) return BBP_ERR_BAD_ARG;
@@ -126,5 +156,60 @@ int32_t bbp_verify(bbp_ctx* c, const uint8_t* rec, uint32_t rec_len, const uint8
     r.in = (const uint8_t*)in.data();
     r.in_len = in.size();
     return c->combiner.submit(c, r);
+}
+
+static void stub_done(bbp::Request* r) {
+    void (*fn)(void*, int32_t) = r->user_fn;
+    void* user = r->user;
+    const int32_t st = r->status;
+    if (st != BBP_OK) t_err = "stub: rejected input";
+    delete r;
+    fn(user, st);
+}
+int32_t bbp_prove_async(bbp_ctx* c, const uint8_t s7[7 * 32], const uint8_t* pub, uint32_t N, uint64_t toggle, const uint8_t* ent, uint8_t* out,
+                        bbp_done_fn done, void* user) {
+    if (N == 0) return BBP_ERR_BAD_ARG;
+    if (N > BBP_MAX_ITEMS) return BBP_ERR_GENS_LEN;
+    bbp::Request* r = new bbp::Request();
+    r->own_in.assign(s7, s7 + 7 * 32);
+    r->own_in.insert(r->own_in.end(), pub, pub + 32 * (size_t)N);
+    r->own_in.insert(r->own_in.end(), (const uint8_t*)&toggle, (const uint8_t*)&toggle + 8);
+    r->kind = 0;
+    r->N = N;
+    r->in = r->own_in.data();
+    r->in_len = r->own_in.size();
+    r->entropy = ent;
+    r->out = out;
+    r->on_done = stub_done;
+    r->user_fn = done;
+    r->user = user;
+    if (!c->combiner.submit_async(c, r)) {
+        delete r;
+        return BBP_ERR_INTERNAL;
+    }
+    return BBP_OK;
+}
+int32_t bbp_verify_async(bbp_ctx* c, const uint8_t* rec, uint32_t rec_len, const uint8_t score[32], const uint8_t z[32], const uint8_t seed[32],
+                         const uint8_t* pub, uint32_t N, bbp_done_fn done, void* user) {
+    if (rec_len != 1121 + 32 * (4 + N)) return BBP_ERR_FORMAT;
+    if (!canonical(score) || !canonical(z) || !canonical(seed)) return BBP_ERR_FORMAT;
+    bbp::Request* r = new bbp::Request();
+    r->own_in.assign(rec, rec + rec_len);
+    r->own_in.insert(r->own_in.end(), score, score + 32);
+    r->own_in.insert(r->own_in.end(), z, z + 32);
+    r->own_in.insert(r->own_in.end(), seed, seed + 32);
+    r->own_in.insert(r->own_in.end(), pub, pub + 32 * (size_t)N);
+    r->kind = 1;
+    r->N = N;
+    r->in = r->own_in.data();
+    r->in_len = r->own_in.size();
+    r->on_done = stub_done;
+    r->user_fn = done;
+    r->user = user;
+    if (!c->combiner.submit_async(c, r)) {
+        delete r;
+        return BBP_ERR_INTERNAL;
+    }
+    return BBP_OK;
 }
 }

@@ -4,6 +4,8 @@ pre-encoded synthetic bids, runs bbp-uds-loadgen with C closed-loop connections 
 BenchmarkProveVerify's shape), prints the load generator's JSON line plus the server's batching statistics.
 
     python tools/uds_bench.py [--connections 2048] [--ops 16384] [--items 8] [--window-us 300] [--max-batch 1024] [--stub]
+    python tools/uds_bench.py --rate 12000 --duration 10 [--connections 8192]     # open loop: Poisson arrivals at a fixed offered load
+    python tools/uds_bench.py --sweep 4000,8000,12000,16000,18000 --duration 8     # latency-vs-offered-load table (one JSON line per point)
 """
 import argparse, json, os, re, signal, struct, subprocess, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,7 +23,12 @@ def main():
     ap.add_argument("--window-us", type=int, default=300)
     ap.add_argument("--max-batch", type=int, default=1024)
     ap.add_argument("--no-verify", action="store_true")
-    ap.add_argument("--reconnect", action="store_true")
+    ap.add_argument("--rate", type=float, default=0.0, help="open loop: offered ops per second (Poisson arrivals)")
+    ap.add_argument("--duration", type=float, default=10.0, help="open loop: seconds of arrivals")
+    ap.add_argument("--sweep", default="", help="open loop: comma-separated offered loads, one run each against the same server")
+    ap.add_argument("--io-threads", type=int, default=2)
+    ap.add_argument("--gen-threads", type=int, default=2)
+    ap.add_argument("--devices", default="0", help="server --devices list (a,b,..: device pool)")
     ap.add_argument("--stub", action="store_true", help="CPU box: the tests' stub engine (plumbing check, not a measurement)")
     a = ap.parse_args()
     ge.build_server()
@@ -51,7 +58,8 @@ def main():
             f.write(struct.pack("<I", len(pf)) + pf + struct.pack("<I", len(vt)) + vt)
     log = open(os.path.join(d, "server.log"), "w+")
     srv = subprocess.Popen([ge.SERVER_BIN, "-b", sock, "-l", "info", "--engine", engine, "--window-us", str(a.window_us), "--max-batch",
-                            str(a.max_batch), "--max-connections", str(max(4096, 2 * a.connections))], stderr=log)
+                            str(a.max_batch), "--max-connections", str(max(4096, 2 * a.connections)), "--io-threads", str(a.io_threads),
+                            "--devices", a.devices], stderr=log)
     for _ in range(3000):
         if os.path.exists(sock) or srv.poll() is not None:
             break
@@ -59,23 +67,33 @@ def main():
     if not os.path.exists(sock):
         log.seek(0)
         sys.exit("server did not come up: " + log.read()[-500:])
-    cmd = [ge.LOADGEN_BIN, "--socket", sock, "--requests", reqs, "--connections", str(a.connections)]
+    cmd = [ge.LOADGEN_BIN, "--socket", sock, "--requests", reqs, "--connections", str(a.connections), "--threads", str(a.gen_threads)]
+    extra = ["--no-verify"] if a.no_verify else []
     warm = subprocess.run(cmd + ["--ops", str(min(a.ops, 2 * a.connections))], capture_output=True, text=True)  # compile the circuit, grow buffers
-    run = subprocess.run(cmd + ["--ops", str(a.ops)] + (["--no-verify"] if a.no_verify else []) + (["--reconnect"] if a.reconnect else []),
-                         capture_output=True, text=True)
+    runs = []
+    if a.sweep or a.rate > 0:
+        for r in ([float(x) for x in a.sweep.split(",")] if a.sweep else [a.rate]):
+            runs.append(subprocess.run(cmd + ["--rate", str(r), "--duration", str(a.duration)] + extra, capture_output=True, text=True))
+    else:
+        runs.append(subprocess.run(cmd + ["--ops", str(a.ops)] + extra, capture_output=True, text=True))
     srv.send_signal(signal.SIGTERM)
-    srv.wait(timeout=30)
+    srv.wait(timeout=60)
     log.seek(0)
     if os.environ.get("BBP_TRACE"):
         sys.stderr.write("".join([ln for ln in log.read().splitlines(True) if "trace" in ln][-40:]))
         log.seek(0)
-    m = re.search(r"served (\d+) requests \((\d+) errors\) in (\d+) device calls, largest batch (\d+)", log.read())
-    out = json.loads(run.stdout.strip().splitlines()[-1]) if run.stdout.strip() else {"error": run.stderr[-300:], "warmup": warm.stderr[-300:]}
-    out.update(workload="configs[4] through the UDS server: closed-loop prove+verify per connection", bid_list_len=N, window_us=a.window_us,
-               max_batch=a.max_batch, engine="stub (not a measurement)" if a.stub else "libbbp_hip.so")
-    if m:
-        out["server"] = dict(requests=int(m.group(1)), errors=int(m.group(2)), device_calls=int(m.group(3)), largest_batch=int(m.group(4)))
-    print(json.dumps(out))
+    text = log.read()
+    m = re.search(r"served (\d+) requests \((\d+) errors\) in (\d+) device calls, largest batch (\d+)", text)
+    for run in runs:
+        out = json.loads(run.stdout.strip().splitlines()[-1]) if run.stdout.strip() else {"error": run.stderr[-300:], "warmup": warm.stderr[-300:]}
+        out.update(workload="configs[4] through the UDS server: %s per connection" % ("prove only" if a.no_verify else "prove then verify"), bid_list_len=N,
+                   window_us=a.window_us, max_batch=a.max_batch, io_threads=a.io_threads, devices=a.devices,
+                   engine="stub (not a measurement)" if a.stub else "libbbp_hip.so")
+        if m and len(runs) == 1:
+            out["server"] = dict(requests=int(m.group(1)), errors=int(m.group(2)), device_calls=int(m.group(3)), largest_batch=int(m.group(4)))
+        print(json.dumps(out), flush=True)
+    if "ERROR" in text and os.environ.get("BBP_SHOW_SERVER_ERRORS"):
+        sys.stderr.write(text[-2000:])
 
 
 if __name__ == "__main__":
