@@ -49,6 +49,7 @@ SIGNATURES = {
     "bbp_prepare_bids_dev": (_i32, [_vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "bbp_verify_batch_aggregated": (_i32, [_vp, _u32, _u32, _vp, _vp, _u32, _vp]),
     "bbp_verify_batch_aggregated_dev": (_i32, [_vp, _u32, _u32, _vp, _vp, _vp, _u32, _vp, _vp]),
+    "bbp_reserve": (_i32, [_vp, _u32, _u32]),
     "bbp_set_batching": (_i32, [_vp, _u32, _u32]),
     "bbp_batching_stats": (_i32, [_vp, ctypes.POINTER(_u64), ctypes.POINTER(_u64), ctypes.POINTER(_u32)]),
     "bbp_debug_compile_circuit": (_i32, [_u32, ctypes.POINTER(_u32), ctypes.POINTER(_u32)]),
@@ -262,6 +263,10 @@ class Context:
     def verify_stream(self, lane):
         """hipStream_t handle of verifier lane 0 / 1: verification calls on the two lanes' streams overlap on the device."""
         return lib.bbp_context_verify_stream(self._h, lane)
+
+    def reserve(self, max_batch, N):
+        """Grow every per-batch buffer to what batches of up to max_batch items of list length N need (bbp_reserve)."""
+        self._check(lib.bbp_reserve(self._h, max_batch, N))
 
     def set_batching(self, window_us=0, max_batch=0):
         """Micro-batching window / size bound of the call combiner (concurrent prove() / verify() callers share device batches)."""

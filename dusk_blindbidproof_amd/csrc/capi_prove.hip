@@ -4,6 +4,7 @@
 #include <unistd.h>
 
 #include <chrono>
+#include <thread>
 
 #include "batch.h"
 #include "submit.h"
@@ -221,9 +222,10 @@ namespace bbp {
 struct SlotLease {
     bbp_ctx* ctx;
     bbp_ctx::IoSlot* sl;
-    explicit SlotLease(bbp_ctx* c) : ctx(c) {
+    explicit SlotLease(bbp_ctx* c, bool verify = false) : ctx(c) {
         std::unique_lock<std::mutex> lk(c->io_mu);
-        const uint32_t want = c->io_next++ % bbp_ctx::IO_SLOTS;  // strict rotation keeps consecutive calls on different slots
+        // strict rotation keeps consecutive calls on different slots; prove and verify calls have their own
+        const uint32_t want = verify ? bbp_ctx::IO_SLOTS + c->io_vnext++ % bbp_ctx::IO_VSLOTS : c->io_next++ % bbp_ctx::IO_SLOTS;
         c->io_cv.wait(lk, [&] { return !c->io[want].busy; });
         sl = &c->io[want];
         sl->busy = true;
@@ -526,9 +528,9 @@ static int32_t verify_batch_host(bbp_ctx* ctx, uint32_t B, uint32_t N, uint32_t 
         api_guard(ctx, [&]() -> int32_t { return ctx->err = "cannot read /dev/urandom", BBP_ERR_DEVICE; });
         return BBP_ERR_DEVICE;
     }
-    SlotLease lease(ctx);
+    SlotLease lease(ctx, true);
     bbp_ctx::IoSlot& sl = *lease.sl;
-    bbp_ctx::VLane& L = ctx->vl[(&sl - ctx->io) % bbp_ctx::VLANES];  // verifier lane = staging slot: consecutive host calls overlap on the device
+    bbp_ctx::VLane& L = ctx->vl[(&sl - ctx->io) - bbp_ctx::IO_SLOTS];  // verifier lane = staging slot: consecutive host calls overlap on the device
     int32_t rc = api_guard(ctx, [&]() -> int32_t {
         int32_t rc;
         BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -710,6 +712,46 @@ extern "C" int32_t bbp_verify_async(bbp_ctx* ctx, const uint8_t* record, uint32_
         }
         return BBP_OK;
     }, ctx);
+}
+
+// Grow every per-batch buffer of the context to what batches of `max_batch` need, by running the real paths once per staging
+// slot / buffer parity on all-zero dummy rows (a zero row is a well-formed request: canonical scalars, toggle 0): whatever a
+// later batch of at most that size touches -- batch buffers in rotation, MSM scratch per slice, draw buffers, staging slots and
+// their pinned mirrors, the compiled circuit of list length N -- exists afterwards, so no call pays for (and no neighbour stalls
+// behind) a hipFree + hipMalloc of gigabytes: growing scratch under load was measured through the UDS server as one ~0.9 s stall
+// per run, i.e. the whole p99.
+extern "C" int32_t bbp_reserve(bbp_ctx* ctx, uint32_t max_batch, uint32_t N) {
+    if (!ctx) return BBP_ERR_BAD_ARG;
+    int32_t rc = api_guard(ctx, [&]() -> int32_t { return check_n(ctx, N); });
+    if (rc || max_batch == 0) return rc;
+    if (is_pool(ctx)) {  // every member, all at once
+        std::vector<int32_t> rcs(ctx->members.size(), BBP_OK);
+        std::vector<std::thread> th;
+        for (size_t i = 0; i < ctx->members.size(); i++) {
+            try {
+                th.emplace_back([&, i] { rcs[i] = bbp_reserve(ctx->members[i], max_batch, N); });
+            } catch (...) {
+                rcs[i] = bbp_reserve(ctx->members[i], max_batch, N);
+            }
+        }
+        for (auto& t : th) t.join();
+        for (int32_t r : rcs)
+            if (r) return r;
+        return BBP_OK;
+    }
+    return no_throw_ctx(ctx, [&]() -> int32_t {
+        const uint32_t B = max_batch;
+        const size_t in_stride = 7 * 32 + (size_t)N * 32 + 8, rec = bbp_proof_record_size(N), v_stride = rec + 96 + (size_t)N * 32;
+        std::vector<uint8_t> in(in_stride * B, 0), ent((size_t)bbp_entropy_size(N) * B, 0), out(rec * B), vin(v_stride * B, 0);
+        std::vector<int32_t> st(B);
+        int32_t rc = BBP_OK;
+        // batches below 1024 proofs rotate three buffers and two opening streams, larger ones two buffers: both shapes, every slot
+        for (int k = 0; k < bbp_ctx::IO_SLOTS && rc == BBP_OK; k++) rc = prove_batch_host(ctx, B, N, in.data(), ent.data(), out.data(), st.data());
+        const uint32_t small = B < 1023 ? B : 1023;
+        for (int k = 0; k < bbp_ctx::PROVE_BUFS && rc == BBP_OK && B >= 1024; k++) rc = prove_batch_host(ctx, small, N, in.data(), ent.data(), out.data(), st.data());
+        for (int k = 0; k < bbp_ctx::IO_VSLOTS && rc == BBP_OK; k++) rc = verify_batch_host(ctx, B, N, 0, vin.data(), st.data());
+        return rc;
+    });
 }
 
 extern "C" int32_t bbp_set_batching(bbp_ctx* ctx, uint32_t window_us, uint32_t max_batch) {

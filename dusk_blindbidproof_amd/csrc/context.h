@@ -168,11 +168,12 @@ struct bbp_ctx {
         hipEvent_t ev = nullptr, ev_in = nullptr;
         bool busy = false;
     };
-    static constexpr int IO_SLOTS = 3;
-    IoSlot io[IO_SLOTS];
+    static constexpr int IO_SLOTS = 3;           // prove calls rotate over slots 0..2
+    static constexpr int IO_VSLOTS = VLANES;     // verify calls over their own slots 3..4 (= verifier lane 0 / 1): a verification never
+    IoSlot io[IO_SLOTS + IO_VSLOTS];             // waits for a slot that a 100 ms prove call is holding
     std::mutex io_mu;
     std::condition_variable io_cv;
-    uint32_t io_next = 0;
+    uint32_t io_next = 0, io_vnext = 0;
     std::map<uint32_t, void*> circuits;  // N -> CircuitDev* (compiled blind-bid circuit tables on the device)
     std::map<uint64_t, bbp::u32*> layout_idx;  // (layout << 32 | n_terms) -> device base-index list of bbp_msm_batch (capi_msm.hip)
     std::vector<float> timings;

@@ -142,6 +142,12 @@ static int32_t init_body(int32_t device, bbp_ctx** out) {
     {  // the prover's opening stage lasts ~36 ms whatever the batch size: a second batch starts no earlier
         const char* e = getenv("BBP_BATCH_STAGGER_US");
         static_cast<Combiner*>(ctx->combiner)->set_stagger(e ? (uint32_t)atoi(e) : 35000u);
+        const char* sp = getenv("BBP_BATCH_SPLIT_MIN");  // 1024: halves that still run at the engine's large-batch rate
+        static_cast<Combiner*>(ctx->combiner)->set_split_min(sp ? (uint32_t)atoi(sp) : 1024u);
+        const char* qc = getenv("BBP_BATCH_QUIET_CAP_US");  // a next batch's opening stage (~40 ms) fits under a 1024-proof MSM stage (~48 ms) with 8 ms to spare
+        static_cast<Combiner*>(ctx->combiner)->set_quiet(300, qc ? (uint32_t)atoi(qc) : 8000u);
+        const char* hm = getenv("BBP_BATCH_HOLD_MARGIN_US");  // -1 = off
+        static_cast<Combiner*>(ctx->combiner)->set_hold(hm ? atoi(hm) : 4000, 40000u, 48.0);  // ~40 ms opening stage, ~48 us per proof
     }
     BBP_HIP_TRY(ctx, hipSetDevice(device));
     hipDeviceProp_t prop;

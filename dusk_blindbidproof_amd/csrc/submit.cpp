@@ -32,6 +32,24 @@ void Combiner::set_stagger(uint32_t us) {
     stagger_us_ = us;
 }
 
+void Combiner::set_quiet(uint32_t quiet_us, uint32_t cap_us) {
+    std::lock_guard<std::mutex> lk(mu_);
+    quiet_us_ = quiet_us ? quiet_us : 1;
+    quiet_cap_us_ = cap_us;
+}
+
+void Combiner::set_hold(int32_t margin_us, uint32_t open_us, double per_proof_us) {
+    std::lock_guard<std::mutex> lk(mu_);
+    hold_margin_us_ = margin_us;
+    open_us_ = open_us;
+    per_proof_us_ = per_proof_us;
+}
+
+void Combiner::set_split_min(uint32_t n) {
+    std::lock_guard<std::mutex> lk(mu_);
+    split_min_ = n;
+}
+
 void Combiner::stats(uint64_t* n_calls, uint64_t* n_requests, uint32_t* max_seen) {
     std::lock_guard<std::mutex> lk(mu_);
     if (n_calls) *n_calls = n_calls_;
@@ -60,13 +78,13 @@ void Combiner::target_stats(size_t i, uint64_t* n_calls, uint64_t* n_requests) {
 }
 
 // least-loaded target; ties go round-robin so that an idle pool is used evenly
-size_t Combiner::pick_target_locked() {
+size_t Combiner::pick_target_locked(int kind) {
     size_t best = 0;
     int best_load = 1 << 30;
     for (size_t k = 0; k < targets_.size(); k++) {
         const size_t i = (rr_ + k) % targets_.size();
-        if (targets_[i].running < best_load) {
-            best_load = targets_[i].running;
+        if (targets_[i].running[kind] < best_load) {
+            best_load = targets_[i].running[kind];
             best = i;
         }
     }
@@ -79,8 +97,10 @@ Combiner::~Combiner() {
         std::lock_guard<std::mutex> lk(mu_);
         stop_ = true;
     }
-    cv_work_.notify_all();
-    cv_window_.notify_all();
+    for (Lane& L : lane_) {
+        L.cv_work.notify_all();
+        L.cv_window.notify_all();
+    }
     for (auto& t : threads_) t.join();
 }
 
@@ -92,17 +112,20 @@ bool Combiner::enqueue_locked(bbp_ctx* ctx, Request* r) {
         t.ctx = ctx;
         targets_.push_back(t);
     }
-    while ((int)threads_.size() < max_leaders_locked()) {
-        try {
-            threads_.emplace_back([this] { thread_main(); });
+    const int kind = r->kind ? 1 : 0;
+    Lane& L = lane_[kind];
+    while (L.n_threads < max_leaders_locked()) {  // prove and verify requests have their own queue and their own batch threads:
+        try {                                     // a verification never waits for a thread that sits in a 100 ms prove call
+            threads_.emplace_back([this, kind] { thread_main(kind); });
+            L.n_threads++;
         } catch (...) {
             break;
         }
     }
-    if (threads_.empty()) return false;
-    q_.push_back(r);
-    if (idle_ > 0) cv_work_.notify_one();
-    if (q_.size() >= max_batch_) cv_window_.notify_all();  // a thread in its window / holding back has a full batch now
+    if (L.n_threads == 0) return false;
+    L.q.push_back(r);
+    if (L.idle > 0) L.cv_work.notify_one();
+    if (L.q.size() >= max_batch_) L.cv_window.notify_all();  // a thread in its window / holding back has a full batch now
     return true;
 }
 
@@ -122,12 +145,15 @@ bool Combiner::submit_async(bbp_ctx* ctx, Request* r) {
     return enqueue_locked(ctx, r);
 }
 
-void Combiner::thread_main() {
+void Combiner::thread_main(int kind) {
+    Lane& L = lane_[kind];
+    std::deque<Request*>& q_ = L.q;
+    std::condition_variable& cv_window_ = L.cv_window;
     std::unique_lock<std::mutex> lk(mu_);
     for (;;) {
-        idle_++;
-        cv_work_.wait(lk, [&] { return stop_ || !q_.empty(); });
-        idle_--;
+        L.idle++;
+        L.cv_work.wait(lk, [&] { return stop_ || !q_.empty(); });
+        L.idle--;
         if (stop_) return;
         // Optional window: give concurrent callers a moment to join this batch.
         if (window_us_) {
@@ -138,17 +164,38 @@ void Combiner::thread_main() {
             if (q_.empty()) continue;  // another thread took everything meanwhile
         }
         // reserve the least-loaded target now (under the lock), so that two threads never count on the same idle device
-        const size_t ti = pick_target_locked();
-        size_t idle_targets = 0;  // targets with nothing reserved, this one included if so: what a burst should spread over
-        for (const Target& t : targets_) idle_targets += t.running == 0;
-        targets_[ti].running++;
+        const size_t ti = pick_target_locked(kind);
+        size_t idle_targets = 0;  // targets with nothing (of this kind) reserved, this one included if so: what a burst should spread over
+        for (const Target& t : targets_) idle_targets += t.running[kind] == 0;
+        targets_[ti].running[kind]++;
         if (stagger_us_ && targets_[ti].prove_inflight > 0 && q_.front()->kind == 0) {  // a PROVE batch is on that device and this would be another:
             // let it grow until that one's opening stage is over (verifications have no such stage and never wait here)
             const auto start_at = targets_[ti].last_start + std::chrono::microseconds(stagger_us_);
             while (!stop_ && targets_[ti].prove_inflight > 0 && q_.size() < max_batch_ && wait_until_steady(cv_window_, lk, start_at) != std::cv_status::timeout) {
             }
+            // ... nor before its own MSM stage could start anyway: the batch in flight is expected to end at est_end (below), this
+            // batch's opening stage takes open_us_, so leaving earlier than est_end - open_us_ only means leaving SMALLER -- through
+            // the UDS server, 3072 closed-loop connections: a thread woken by the first few returning callers left with 65 proofs
+            // and held a pipeline slot for 90 ms while 1400 more queued up behind it.
+            if (hold_margin_us_ >= 0) {
+                const auto hold_until = targets_[ti].est_end - std::chrono::microseconds(open_us_ + hold_margin_us_);
+                while (!stop_ && targets_[ti].prove_inflight > 0 && q_.size() < max_batch_ && wait_until_steady(cv_window_, lk, hold_until) != std::cv_status::timeout) {
+                }
+            }
+            // ... and while the queue is still GROWING behind a busy device, keep holding back (quiet-period detection, bounded): the
+            // callers of a batch that just finished come back as a burst spread over milliseconds -- 1536 replies written and
+            // answered one after the other -- and a thread that left with the first few hundred of them would put a small,
+            // inefficient batch in front of the large one that is forming (closed loop, 3072 connections: average batch 1014 of a
+            // possible 1536).  Nothing is lost by waiting: this batch's MSM stage cannot start before the one in flight ends.
+            const auto quiet_cap = std::chrono::steady_clock::now() + std::chrono::microseconds(quiet_cap_us_);
+            while (!stop_ && quiet_cap_us_ && targets_[ti].prove_inflight > 0 && q_.size() < max_batch_) {
+                const size_t before = q_.size();
+                const auto tick = std::min(quiet_cap, std::chrono::steady_clock::now() + std::chrono::microseconds(quiet_us_));
+                wait_until_steady(cv_window_, lk, tick);
+                if (q_.size() == before || std::chrono::steady_clock::now() >= quiet_cap) break;
+            }
             if (stop_ || q_.empty()) {
-                targets_[ti].running--;
+                targets_[ti].running[kind]--;
                 if (stop_) return;
                 continue;
             }
@@ -163,6 +210,16 @@ void Combiner::thread_main() {
             const size_t share = (n_class + idle_targets - 1) / idle_targets;
             limit = std::min<size_t>(limit, std::max<size_t>(share, MIN_SHARE));
         }
+        if (head->kind == 0 && targets_[ti].prove_inflight == 0 && split_min_) {
+            // The device holds no prove batch: whatever is queued would go out as ONE batch whose opening stage (~40 ms of serial
+            // transcript work) runs beside nothing, and -- closed-loop callers -- come back as one synchronised burst again.  A burst
+            // of at least two full-efficiency batches is cut in half instead: the second half follows a stagger later, its opening
+            // runs under the first half's MSM stage, and the two halves' callers return out of phase from then on (the engine's
+            // cross-call pipeline stays full: 3072 connections prove-only through the socket 13.3 k -> see DESIGN.md 6c).
+            size_t n_class = 0;
+            for (const Request* q : q_) n_class += same_class(q, head);
+            if (n_class >= 2 * (size_t)split_min_) limit = std::min<size_t>(limit, std::max<size_t>((n_class + 1) / 2, split_min_));
+        }
         std::vector<Request*> batch;
         for (auto it = q_.begin(); it != q_.end() && batch.size() < limit;) {
             if (same_class(*it, head)) {
@@ -172,18 +229,24 @@ void Combiner::thread_main() {
                 ++it;
             }
         }
-        if (!q_.empty() && idle_ > 0) cv_work_.notify_one();  // another class, or the rest of a burst: not this thread's batch
+        if (!q_.empty() && L.idle > 0) L.cv_work.notify_one();  // another class, or the rest of a burst: not this thread's batch
         const bool proving = batch[0]->kind == 0;  // prove_inflight / last_start track prove batches only
         if (proving) {
+            const auto now = std::chrono::steady_clock::now();
+            // expected end of this batch: its MSM stage (per_proof_us_ each) starts when its opening stage is over AND the batch in
+            // flight has ended.  An estimate only: it decides how long the NEXT batch may keep growing.
+            const auto opened = now + std::chrono::microseconds(open_us_);
+            const auto base = targets_[ti].prove_inflight > 0 && targets_[ti].est_end > opened ? targets_[ti].est_end : opened;
+            targets_[ti].est_end = base + std::chrono::microseconds((long long)(per_proof_us_ * (double)batch.size()));
             targets_[ti].prove_inflight++;
-            targets_[ti].last_start = std::chrono::steady_clock::now();
+            targets_[ti].last_start = now;
         }
         bbp_ctx* const where = targets_[ti].ctx;
         lk.unlock();
         run_batch(where, batch);
         lk.lock();
         if (proving) targets_[ti].prove_inflight--;
-        targets_[ti].running--;
+        targets_[ti].running[kind]--;
         cv_window_.notify_all();  // a thread holding back behind this batch may go now
         n_calls_++;
         n_requests_ += batch.size();

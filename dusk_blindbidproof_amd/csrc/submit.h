@@ -77,34 +77,52 @@ class Combiner {
     // the length of the opening stage (the next batch's opening cannot begin earlier anyway), and meanwhile the batch grows --
     // without it a few hundred closed-loop callers fragment into many small batches that each pay the full latency floor.
     void set_stagger(uint32_t us);
+    // Behind a busy device a prove batch leaves only when the queue has stopped growing for `quiet_us`, at most `cap_us` after its
+    // stagger is over (0 = off).
+    void set_quiet(uint32_t quiet_us, uint32_t cap_us);
+    // Behind a prove batch in flight the next one leaves no earlier than (expected end of that batch) - open_us - margin_us, where a
+    // batch of B proofs is expected to take open_us (opening stage) + per_proof_us * B once the device is its own.  margin_us < 0 = off.
+    void set_hold(int32_t margin_us, uint32_t open_us, double per_proof_us);
+    // A prove burst that finds its device idle and holds at least 2 n requests is cut in two (each half >= n): 0 = never.
+    void set_split_min(uint32_t n);
     void stats(uint64_t* n_calls, uint64_t* n_requests, uint32_t* max_seen);
 
   private:
     void run_batch(bbp_ctx* ctx, std::vector<Request*>& batch);
     struct Target {
         bbp_ctx* ctx = nullptr;
-        int running = 0;         // combined calls reserved / running on this target (any kind)
+        int running[2] = {0, 0};  // combined calls reserved / running on this target, per kind (0 = prove, 1 = verify)
         int prove_inflight = 0;  // prove batches among them
         std::chrono::steady_clock::time_point last_start{};  // start of the last prove batch (stagger)
+        std::chrono::steady_clock::time_point est_end{};     // when the prove batches dealt to this target so far are expected to be done
         uint64_t n_calls = 0, n_requests = 0;
     };
     std::vector<Target> targets_;  // empty until the first submit of a plain context (then: that context)
     size_t rr_ = 0;                // tie-break cursor
-    size_t pick_target_locked();
+    size_t pick_target_locked(int kind);
     static constexpr uint32_t MIN_SHARE = 64;  // a fair share is never cut below this many requests: tiny batches pay the full latency floor
     std::mutex mu_;
-    std::condition_variable cv_window_;  // arrivals -> a batch thread that sits in its batching window / holds back behind a prove batch
-    std::condition_variable cv_work_;    // arrivals -> an idle batch thread
-    std::deque<Request*> q_;
+    // one queue and one set of batch threads per request kind (0 = prove, 1 = verify): the engine runs the two on disjoint
+    // scratch and streams, so a verification batch neither waits for a thread that is inside a prove call nor queues behind
+    // prove requests (measured through the UDS server, closed loop 2048 connections: verify p50 25-47 ms with shared threads)
+    struct Lane {
+        std::deque<Request*> q;
+        std::condition_variable cv_window;  // arrivals -> a batch thread that sits in its batching window / holds back behind a prove batch
+        std::condition_variable cv_work;    // arrivals -> an idle batch thread
+        int idle = 0;                       // batch threads waiting for work
+        int n_threads = 0;
+    };
+    Lane lane_[2];
     std::vector<std::thread> threads_;
-    int idle_ = 0;       // batch threads waiting for work
     bool stop_ = false;
     bool enqueue_locked(bbp_ctx* ctx, Request* r);
-    void thread_main();
+    void thread_main(int kind);
     static constexpr int LEADERS_PER_TARGET = 2;  // three (as many as there are staging slots) fragments closed-loop load into more, smaller batches:
                                                   // measured through the UDS server 14.7 k -> 11.5 k proofs/s prove-only, 8.2 k -> 7.1 k ops/s at 2048 connections
     int max_leaders_locked() const { return LEADERS_PER_TARGET * (int)(targets_.empty() ? 1 : targets_.size()); }
-    uint32_t window_us_ = 0, max_batch_ = 4096, stagger_us_ = 0;
+    uint32_t window_us_ = 0, max_batch_ = 4096, stagger_us_ = 0, split_min_ = 0, quiet_us_ = 300, quiet_cap_us_ = 0, open_us_ = 40000;
+    int32_t hold_margin_us_ = -1;
+    double per_proof_us_ = 48.0;
     uint64_t n_calls_ = 0, n_requests_ = 0;
     uint32_t max_seen_ = 0;
 };

@@ -16,6 +16,7 @@
 // frame, read the proof frame, wrap it into an opcode-2 request with the bid's tail, expect [0x01].
 // Prints one JSON line: ops/s, proofs/s, latency percentiles of prove, verify and the whole op.
 #include <errno.h>
+#include <fcntl.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -56,7 +57,15 @@ static bool write_all(int fd, const uint8_t* p, size_t n) {  // blocking send: r
     }
     return true;
 }
+static std::atomic<long> g_dial_retries{0}, g_dial_us{0};
+static int dial_inner(const std::string& path);
 static int dial(const std::string& path) {
+    const auto t0 = Clock::now();
+    const int fd = dial_inner(path);
+    g_dial_us += std::chrono::duration_cast<std::chrono::microseconds>(Clock::now() - t0).count();
+    return fd;
+}
+static int dial_inner(const std::string& path) {
     int fd = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0);
     if (fd < 0) return -1;
     sockaddr_un a;
@@ -66,6 +75,7 @@ static int dial(const std::string& path) {
     for (int tries = 0; tries < 400; tries++) {
         if (connect(fd, (sockaddr*)&a, sizeof a) == 0) return fd;
         if (errno != EAGAIN && errno != ECONNREFUSED) break;
+        g_dial_retries++;
         usleep(2000);  // listen backlog full while thousands of connections arrive at once
     }
     close(fd);
@@ -95,10 +105,12 @@ struct Worker {
     std::vector<Conn> conns;
     std::vector<int> idle;  // indices into conns
     std::vector<float> lat_p, lat_v, lat_o;
+    std::vector<double> t_done;  // completion time of every op, seconds on the steady clock
     // open loop
     double rate = 0;
     double duration = 0;
     int cap = 0;
+    int preconnect = 0;  // open loop: connections opened before the clock starts (a population of clients with persistent connections)
     std::deque<Clock::time_point> backlog;
     size_t max_backlog = 0;
     long arrivals = 0;
@@ -152,6 +164,7 @@ struct Worker {
     }
     void op_done(int ci) {
         Conn& c = conns[(size_t)ci];
+        t_done.push_back(std::chrono::duration<double>(Clock::now().time_since_epoch()).count());
         c.st = IDLE;
         active--;
         idle.push_back(ci);
@@ -236,6 +249,8 @@ struct Worker {
     void run_open(unsigned seed) {
         std::mt19937_64 rng(seed);
         std::exponential_distribution<double> gap(rate);
+        for (int i = 0; i < preconnect && i < cap; i++)
+            if (!add_conn()) break;
         const auto T0 = Clock::now();
         auto next_arrival = T0 + std::chrono::duration_cast<Clock::duration>(std::chrono::duration<double>(gap(rng)));
         const auto T_end = T0 + std::chrono::duration_cast<Clock::duration>(std::chrono::duration<double>(duration));
@@ -274,7 +289,7 @@ struct Worker {
 int main(int argc, char** argv) {
     Shared sh;
     std::string file;
-    int conns = 64, threads = 2;
+    int conns = 64, threads = 2, preconnect = 0;
     double rate = 0, duration = 10;
     sh.ops = 1024;
     for (int i = 1; i < argc; i++) {
@@ -286,6 +301,7 @@ int main(int argc, char** argv) {
         else if (a == "--rate" && i + 1 < argc) rate = atof(argv[++i]);
         else if (a == "--duration" && i + 1 < argc) duration = atof(argv[++i]);
         else if (a == "--threads" && i + 1 < argc) threads = atoi(argv[++i]);
+        else if (a == "--preconnect" && i + 1 < argc) preconnect = atoi(argv[++i]);
         else if (a == "--no-verify") sh.do_verify = false;
         else {
             fprintf(stderr,
@@ -299,6 +315,10 @@ int main(int argc, char** argv) {
             rl.rlim_cur = rl.rlim_max;
             setrlimit(RLIMIT_NOFILE, &rl);
         }
+    }
+    {  // the descriptor table at its final size before the threads start (a doubling under threads waits for an RCU grace period: ~0.1 s)
+        const int hi = fcntl(0, F_DUPFD_CLOEXEC, conns + 64);
+        if (hi >= 0) close(hi);
     }
     {
         FILE* f = fopen(file.c_str(), "rb");
@@ -331,6 +351,7 @@ int main(int argc, char** argv) {
         ws[(size_t)t].rate = rate / threads;
         ws[(size_t)t].duration = duration;
         ws[(size_t)t].cap = conns / threads + (t < conns % threads ? 1 : 0);
+        ws[(size_t)t].preconnect = preconnect / threads;
     }
     const auto T0 = Clock::now();
     std::vector<std::thread> th;
@@ -342,12 +363,14 @@ int main(int argc, char** argv) {
     for (auto& x : th) x.join();
     const double wall = std::chrono::duration<double>(Clock::now() - T0).count();
     std::vector<float> p, v, o;
+    std::vector<double> td;
     size_t max_backlog = 0, n_conns = 0;
     long arrivals = 0;
     for (auto& w : ws) {
         p.insert(p.end(), w.lat_p.begin(), w.lat_p.end());
         v.insert(v.end(), w.lat_v.begin(), w.lat_v.end());
         o.insert(o.end(), w.lat_o.begin(), w.lat_o.end());
+        td.insert(td.end(), w.t_done.begin(), w.t_done.end());
         max_backlog += w.max_backlog;
         n_conns += w.conns.size();
         arrivals += w.arrivals;
@@ -355,6 +378,14 @@ int main(int argc, char** argv) {
     std::sort(p.begin(), p.end());
     std::sort(v.begin(), v.end());
     std::sort(o.begin(), o.end());
+    // sustained rate: completions between the 10th and the 90th percentile of the run (the ramp -- the first batches form while the
+    // connections are still being opened -- and the tail -- the last, partial batches -- are what a short run adds to wall_s)
+    std::sort(td.begin(), td.end());
+    double sustained = 0;
+    if (td.size() >= 100) {
+        const size_t a = td.size() / 10, b = td.size() - td.size() / 10 - 1;
+        if (td[b] > td[a]) sustained = (double)(b - a) / (td[b] - td[a]);
+    }
     auto at = [](const std::vector<float>& a, double q) { return a.empty() ? 0.f : a[std::min(a.size() - 1, (size_t)(a.size() * q))]; };
     printf("{\"mode\": \"%s\", \"connections\": %zu, \"ops\": %zu, \"wall_s\": %.3f, \"proofs_per_s\": %.1f, \"verifies_per_s\": %.1f, \"failed\": %ld, "
            "\"rejected\": %ld, \"prove_latency_ms\": {\"p50\": %.2f, \"p99\": %.2f}, \"verify_latency_ms\": {\"p50\": %.2f, \"p99\": %.2f}, "
@@ -364,6 +395,7 @@ int main(int argc, char** argv) {
     if (rate > 0)
         printf(", \"offered_per_s\": %.1f, \"duration_s\": %.1f, \"arrivals\": %ld, \"max_client_backlog\": %zu, \"connection_cap\": %d", rate, duration,
                arrivals, max_backlog, conns);
-    printf(", \"generator_threads\": %d}\n", threads);
+    printf(", \"sustained_ops_per_s\": %.1f, \"generator_threads\": %d, \"dial_ms_total\": %.1f, \"dial_retries\": %ld}\n", sustained, threads,
+           g_dial_us.load() / 1e3, g_dial_retries.load());
     return sh.failed.load() || sh.rejected.load() ? 1 : 0;
 }

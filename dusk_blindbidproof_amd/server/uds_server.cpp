@@ -85,6 +85,7 @@ struct Engine {
     decltype(&bbp_set_batching) set_batching = nullptr;
     decltype(&bbp_batching_stats) batching_stats = nullptr;
     decltype(&bbp_check_health) check_health = nullptr;
+    decltype(&bbp_reserve) reserve = nullptr;
     bool load(const char* path, std::string* why) {
         so = dlopen(path, RTLD_NOW | RTLD_LOCAL);
         if (!so) return *why = dlerror(), false;
@@ -104,6 +105,7 @@ struct Engine {
         set_batching = (decltype(set_batching))sym("bbp_set_batching");
         batching_stats = (decltype(batching_stats))sym("bbp_batching_stats");
         check_health = (decltype(check_health))sym("bbp_check_health");
+        reserve = (decltype(reserve))sym("bbp_reserve");
         return why->empty();
     }
 };
@@ -175,6 +177,11 @@ static void on_engine_done(void* user, int32_t status) {
     const uint64_t one = 1;
     (void)!write(r->evfd, &one, 8);
 }
+
+static const bool g_trace = getenv("BBP_TRACE") != nullptr;
+static thread_local double t_submit_max_ms = 0, t_acc_ms = 0, t_comp_ms = 0, t_read_ms = 0;
+static thread_local int t_submits = 0, t_events = 0;
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 void Reactor::set_listening(bool on) {
     if (on == listening || g_listen_fd < 0) return;
@@ -273,7 +280,13 @@ bool Reactor::dispatch(Conn* c, const uint8_t* req, size_t len) {
         p->n_items = pr.n_items;
         p->record.resize(g_eng.record_size(pr.n_items));
         g_inflight++;
+        const double t0 = g_trace ? now_ms() : 0;
         const int32_t rc = g_eng.prove_async(g_eng.ctx, pr.scalars7, pr.pub_list.data(), pr.n_items, pr.toggle, nullptr, p->record.data(), on_engine_done, p);
+        if (g_trace) {
+            const double dt = now_ms() - t0;
+            if (dt > t_submit_max_ms) t_submit_max_ms = dt;
+            t_submits++;
+        }
         if (rc != BBP_OK) {  // decided at once: the callback will not fire
             g_inflight--;
             logf(0, "Error resolving the request: engine status %d: %s", rc, g_eng.last_error(g_eng.ctx));
@@ -414,13 +427,26 @@ void Reactor::complete(Pending* p) {
 void Reactor::run() {
     std::vector<epoll_event> evs(512);
     std::vector<Pending*> batch;
+    double t_iter = now_ms();
     while (!g_stop) {
+        if (g_trace) {  // BBP_TRACE: an iteration of this loop that took long is time during which this thread's connections were not served
+            const double t = now_ms();
+            if (t - t_iter > 10.0)
+                fprintf(stderr, "[bbp trace] reactor %p: iteration took %.1f ms (%d events: accept %.1f ms, completions %.1f ms, reads %.1f ms; %d engine submits, slowest %.1f ms) at %.1f\n",
+                        (void*)this, t - t_iter, t_events, t_acc_ms, t_comp_ms, t_read_ms, t_submits, t_submit_max_ms, t);
+            t_submit_max_ms = t_acc_ms = t_comp_ms = t_read_ms = 0;
+            t_submits = t_events = 0;
+        }
         const int n = epoll_wait(ep, evs.data(), (int)evs.size(), 200);
+        t_iter = now_ms();
+        t_events = n;
         if (n < 0 && errno != EINTR) break;
         for (int i = 0; i < n; i++) {
             const uint64_t id = evs[i].data.u64;
             if (id == 0) {
+                const double a0 = g_trace ? now_ms() : 0;
                 accept_some();
+                if (g_trace) t_acc_ms += now_ms() - a0;
                 continue;
             }
             if (id == UINT64_MAX) {  // completions from the engine
@@ -431,7 +457,9 @@ void Reactor::run() {
                     std::lock_guard<std::mutex> lk(mu);
                     batch.swap(done);
                 }
+                const double c0 = g_trace ? now_ms() : 0;
                 for (Pending* p : batch) complete(p);
+                if (g_trace) t_comp_ms += now_ms() - c0;
                 continue;
             }
             auto it = conns.find(id);
@@ -460,7 +488,9 @@ void Reactor::run() {
                     epoll_ctl(ep, EPOLL_CTL_MOD, c->fd, &ev);
                     continue;
                 }
+                const double r0 = g_trace ? now_ms() : 0;
                 on_readable(c);
+                if (g_trace) t_read_ms += now_ms() - r0;
             }
         }
         if (!listening && !g_stop && g_live.load() < g_max_conn) set_listening(true);
@@ -482,7 +512,7 @@ static void on_signal(int) {
 static void usage(const char* argv0) {
     fprintf(stderr,
             "usage: %s [-b|--bind-path PATH] [-l|--log-level error|warn|info|debug|trace] [--engine LIB.so] [--device N | --devices 0,1,..]\n"
-            "          [--window-us US] [--max-batch B] [--max-connections C] [--io-threads T]\n",
+            "          [--window-us US] [--max-batch B] [--max-connections C] [--io-threads T] [--reserve N[,N..]]\n",
             argv0);
 }
 
@@ -490,7 +520,7 @@ int main(int argc, char** argv) {
     const char* tmp = getenv("TMPDIR");
     std::string bind_path = std::string(tmp && *tmp ? tmp : "/tmp") + "/dusk-uds-blindbid";  // src/main.rs:14-16
     std::string level = "info", engine_path;
-    std::vector<int32_t> devices;
+    std::vector<int32_t> devices, reserve_items;  // --reserve: bid-list lengths whose buffers are sized for --max-batch before the first request
     uint32_t window_us = 200, max_batch = 4096;
     int io_threads = 2;
     for (int i = 1; i < argc; i++) {
@@ -518,6 +548,13 @@ int main(int argc, char** argv) {
         else if (a == "--max-batch") max_batch = (uint32_t)atoi(val());
         else if (a == "--max-connections") g_max_conn = atoi(val());
         else if (a == "--io-threads") io_threads = atoi(val());
+        else if (a == "--reserve") {
+            for (const char* p = val(); *p;) {
+                reserve_items.push_back(atoi(p));
+                while (*p && *p != ',') p++;
+                if (*p == ',') p++;
+            }
+        }
         else {
             usage(argv[0]);
             return 2;
@@ -552,6 +589,11 @@ int main(int argc, char** argv) {
         }
         g_eng.n_devices = devices.size();
         g_eng.set_batching(g_eng.ctx, window_us, max_batch);
+        for (int32_t n : reserve_items) {
+            const int32_t rr = g_eng.reserve(g_eng.ctx, max_batch, (uint32_t)n);
+            if (rr != BBP_OK) logf(1, "--reserve %d: engine status %d: %s (buffers will grow on demand)", n, rr, g_eng.last_error(g_eng.ctx));
+            else logf(2, "buffers sized for batches of %u with bid lists of %d", max_batch, n);
+        }
     }
     {  // every connection is a descriptor: lift the soft limit to the hard one
         rlimit rl;
@@ -560,6 +602,11 @@ int main(int argc, char** argv) {
             setrlimit(RLIMIT_NOFILE, &rl);
         }
         if (getrlimit(RLIMIT_NOFILE, &rl) == 0 && rl.rlim_cur != RLIM_INFINITY && (rlim_t)g_max_conn + 64 > rl.rlim_cur) g_max_conn = (int)rl.rlim_cur - 64;
+        // Grow the descriptor table to its final size NOW.  The kernel doubles it on demand, and in a multi-threaded process every
+        // doubling waits for an RCU grace period inside accept4 (expand_fdtable -> synchronize_rcu): measured here as nine stalls of
+        // 120-190 ms each -- both I/O threads frozen in accept, no request read -- while the first 16 k connections arrived.
+        const int hi = fcntl(0, F_DUPFD_CLOEXEC, g_max_conn + 32);
+        if (hi >= 0) close(hi);
     }
 
     struct sigaction sa;

@@ -209,6 +209,13 @@ int32_t bbp_verify_batch_aggregated(bbp_ctx* ctx, uint32_t B, uint32_t N, const 
 int32_t bbp_verify_batch_aggregated_dev(bbp_ctx* ctx, uint32_t B, uint32_t N, const void* in_dev, const void* entropy_dev,
                                         void* status_dev, uint32_t group, uint32_t* n_fallback, void* stream);
 
+/* Optional, once after bbp_init (or whenever a new list length N shows up): grow every per-batch buffer of the context (every member
+ * of a pool) to what batches of up to max_batch proofs / verifications of list length N need, and compile the circuit for N.
+ * Without it the buffers grow on demand, and a call that finds them too small frees and reallocates gigabytes under load (the
+ * whole device waits: ~0.1-1 s, once per new high-water mark).  Costs about three prove batches of that size; ~1.3 MB of device
+ * memory per proof and buffer. */
+int32_t bbp_reserve(bbp_ctx* ctx, uint32_t max_batch, uint32_t N);
+
 /* Micro-batching window of the call combiner, microseconds (default 0: a batch leaves as soon as the engine is free).  With a
  * window the leader of a batch waits that long for more concurrent bbp_prove / bbp_verify callers before it goes to the device --
  * what the UDS server (server/) uses to turn concurrent connections into GPU batches.  max_batch bounds one combined call. */

@@ -14,12 +14,12 @@
 #include "../dusk_blindbidproof_amd/csrc/submit.h"
 
 struct bbp_ctx {
-    std::atomic<int> inside{0}, max_inside{0}, bad{0};
+    std::atomic<int> inside[2] = {{0}, {0}}, max_inside{0}, bad{0};  // per kind: the combiner runs at most two batches of a kind per target
     uint32_t max_batch = 8;
 };
 
-static void enter(bbp_ctx* c, uint32_t B) {
-    const int n = ++c->inside;
+static void enter(bbp_ctx* c, uint32_t B, int kind) {
+    const int n = ++c->inside[kind];
     int m = c->max_inside.load();
     while (n > m && !c->max_inside.compare_exchange_weak(m, n)) {
     }
@@ -29,20 +29,20 @@ static void enter(bbp_ctx* c, uint32_t B) {
 
 namespace bbp {
 int32_t prove_batch_locked(bbp_ctx* c, uint32_t B, uint32_t N, const uint8_t* in, const uint8_t*, uint8_t* out, int32_t* status, std::string*) {
-    enter(c, B);
+    enter(c, B, 0);
     const size_t stride = 7 * 32 + 32 * (size_t)N + 8, rec = 1121 + 32 * (4 + (size_t)N);
     for (uint32_t i = 0; i < B; i++) {
         status[i] = 0;
         memset(out + rec * i, in[stride * i], rec);  // the record echoes the request's first byte
     }
-    --c->inside;
+    --c->inside[0];
     return 0;
 }
 int32_t verify_batch_locked(bbp_ctx* c, uint32_t B, uint32_t N, uint32_t, const uint8_t* in, int32_t* status, std::string*) {
-    enter(c, B);
+    enter(c, B, 1);
     const size_t stride = 1121 + 32 * (4 + (size_t)N) + 96 + 32 * (size_t)N;
     for (uint32_t i = 0; i < B; i++) status[i] = in[stride * i] & 1;  // "verdict" = low bit of the first byte
-    --c->inside;
+    --c->inside[1];
     return 0;
 }
 }  // namespace bbp

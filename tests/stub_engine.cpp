@@ -2,6 +2,7 @@
 // UDS server binds, so the CPU tier can exercise the server's framing, dispatch, error behaviour and micro-batching without a
 // GPU.  It proves nothing: a "proof" is a tag derived from the public inputs repeated 1120 times, "verification" recomputes the
 // tag.  The call combiner in front of it is the product's own (csrc/submit.cpp, compiled into this library unchanged).
+#include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
 
@@ -16,17 +17,18 @@ struct bbp_ctx {
     bbp::Combiner combiner;
     std::vector<bbp_ctx*> members;  // a stub pool: fake member contexts behind this handle's combiner (bbp_pool_init)
     std::atomic<uint64_t> batch_calls{0};
-    std::atomic<int> inside{0}, max_inside{0};  // combined calls running at the same time (the combiner allows two)
+    std::atomic<int> inside[2] = {{0}, {0}}, max_inside{0};  // combined calls of one kind running at the same time (the combiner allows two per kind)
 };
 struct Inside {
     bbp_ctx* c;
-    explicit Inside(bbp_ctx* ctx) : c(ctx) {
-        const int n = ++c->inside;
+    int kind;
+    Inside(bbp_ctx* ctx, int k) : c(ctx), kind(k) {
+        const int n = ++c->inside[kind];
         int m = c->max_inside.load();
         while (n > m && !c->max_inside.compare_exchange_weak(m, n)) {
         }
     }
-    ~Inside() { --c->inside; }
+    ~Inside() { --c->inside[kind]; }
 };
 
 static thread_local std::string t_err;
@@ -44,8 +46,9 @@ static bool canonical(const uint8_t* s) {  // < 2^253 is enough for a stub: the 
 namespace bbp {
 int32_t prove_batch_locked(bbp_ctx* ctx, uint32_t B, uint32_t N, const uint8_t* in, const uint8_t*, uint8_t* out, int32_t* status, std::string*) {
     ctx->batch_calls++;
-    Inside in_call(ctx);
-    usleep(3000);  // one "device call" costs the same whatever B is: combining is what pays
+    Inside in_call(ctx, 0);
+    static const int prove_us = getenv("STUB_PROVE_US") ? atoi(getenv("STUB_PROVE_US")) : 3000;
+    usleep(prove_us);  // one "device call" costs the same whatever B is: combining is what pays
     const size_t in_stride = 7 * 32 + 32 * (size_t)N + 8, rec = 1121 + 32 * (4 + (size_t)N);
     for (uint32_t i = 0; i < B; i++) {
         const uint8_t* r = in + in_stride * i;
@@ -66,7 +69,7 @@ int32_t prove_batch_locked(bbp_ctx* ctx, uint32_t B, uint32_t N, const uint8_t* 
 }
 int32_t verify_batch_locked(bbp_ctx* ctx, uint32_t B, uint32_t N, uint32_t rec_ver, const uint8_t* in, int32_t* status, std::string*) {
     ctx->batch_calls++;
-    Inside in_call(ctx);
+    Inside in_call(ctx, 1);
     usleep(1000);
     const size_t rec = (rec_ver ? 1217 : 1121) + 32 * (4 + (size_t)N), stride = rec + 96 + 32 * (size_t)N;
     for (uint32_t i = 0; i < B; i++) {
@@ -115,6 +118,7 @@ int32_t bbp_batching_stats(bbp_ctx* c, uint64_t* a, uint64_t* b, uint32_t* m) {
     c->combiner.stats(a, b, m);
     return BBP_OK;
 }
+int32_t bbp_reserve(bbp_ctx*, uint32_t, uint32_t N) { return N == 0 ? BBP_ERR_BAD_ARG : N > BBP_MAX_ITEMS ? BBP_ERR_GENS_LEN : BBP_OK; }
 int32_t bbp_check_health(bbp_ctx*, uint32_t* flags) {
     if (flags) *flags = 0;
     return BBP_OK;

@@ -323,3 +323,24 @@ def test_uds_server_on_a_two_member_pool(ctx, oc, pool_server):
     assert len(per_dev) == 2 and all(int(c) > 0 for _, c, _ in per_dev), log[-1200:]
     assert sum(int(q) for _, _, q in per_dev) == T * per * 3
     assert "ERROR" not in log, log[-1200:]
+
+
+def test_reserve_sizes_buffers_and_changes_no_result(pool, ctx, oc, bbp):
+    """bbp_reserve on a context and on a pool (every member): dummy batches size every per-batch buffer; proofs made afterwards
+    are the oracle's byte for byte, and a second reserve of the same size is a no-op that still succeeds."""
+    N, B = 5, 96
+    for h in (ctx, pool):
+        h.reserve(B, N)
+        h.reserve(B, N)
+    ins, ents, vins = _synth_batch(ctx, B, N, seed=8642)
+    exp, est = oc.prove_many(b"".join(ins), b"".join(ents), B, N, threads=8)
+    assert est == [0] * B
+    for h in (ctx, pool):
+        out, st = h.prove_batch(B, N, b"".join(ins), b"".join(ents))
+        assert st == [0] * B and out == exp
+    with pytest.raises(bbp.BbpError) as e:
+        ctx.reserve(16, 0)
+    assert e.value.status == 4
+    with pytest.raises(bbp.BbpError) as e:
+        pool.reserve(16, 203)
+    assert e.value.status == 2

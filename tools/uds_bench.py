@@ -21,13 +21,14 @@ def main():
     ap.add_argument("--items", type=int, default=8)
     ap.add_argument("--distinct", type=int, default=256)
     ap.add_argument("--window-us", type=int, default=300)
-    ap.add_argument("--max-batch", type=int, default=1024)
+    ap.add_argument("--max-batch", type=int, default=4096)
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--rate", type=float, default=0.0, help="open loop: offered ops per second (Poisson arrivals)")
     ap.add_argument("--duration", type=float, default=10.0, help="open loop: seconds of arrivals")
     ap.add_argument("--sweep", default="", help="open loop: comma-separated offered loads, one run each against the same server")
     ap.add_argument("--io-threads", type=int, default=2)
     ap.add_argument("--gen-threads", type=int, default=2)
+    ap.add_argument("--preconnect", type=int, default=0, help="open loop: connections opened before the clock starts")
     ap.add_argument("--devices", default="0", help="server --devices list (a,b,..: device pool)")
     ap.add_argument("--stub", action="store_true", help="CPU box: the tests' stub engine (plumbing check, not a measurement)")
     a = ap.parse_args()
@@ -59,8 +60,8 @@ def main():
     log = open(os.path.join(d, "server.log"), "w+")
     srv = subprocess.Popen([ge.SERVER_BIN, "-b", sock, "-l", "info", "--engine", engine, "--window-us", str(a.window_us), "--max-batch",
                             str(a.max_batch), "--max-connections", str(max(4096, 2 * a.connections)), "--io-threads", str(a.io_threads),
-                            "--devices", a.devices], stderr=log)
-    for _ in range(3000):
+                            "--devices", a.devices, "--reserve", str(N)], stderr=log)
+    for _ in range(6000):
         if os.path.exists(sock) or srv.poll() is not None:
             break
         time.sleep(0.02)
@@ -73,14 +74,15 @@ def main():
     runs = []
     if a.sweep or a.rate > 0:
         for r in ([float(x) for x in a.sweep.split(",")] if a.sweep else [a.rate]):
-            runs.append(subprocess.run(cmd + ["--rate", str(r), "--duration", str(a.duration)] + extra, capture_output=True, text=True))
+            runs.append(subprocess.run(cmd + ["--rate", str(r), "--duration", str(a.duration), "--preconnect", str(a.preconnect)] + extra,
+                                       capture_output=True, text=True))
     else:
         runs.append(subprocess.run(cmd + ["--ops", str(a.ops)] + extra, capture_output=True, text=True))
     srv.send_signal(signal.SIGTERM)
     srv.wait(timeout=60)
     log.seek(0)
     if os.environ.get("BBP_TRACE"):
-        sys.stderr.write("".join([ln for ln in log.read().splitlines(True) if "trace" in ln][-40:]))
+        sys.stderr.write("".join([ln for ln in log.read().splitlines(True) if "trace" in ln][:int(os.environ.get("BBP_TRACE_HEAD", "0")) or None][-int(os.environ.get("BBP_TRACE_TAIL", "40")):]))
         log.seek(0)
     text = log.read()
     m = re.search(r"served (\d+) requests \((\d+) errors\) in (\d+) device calls, largest batch (\d+)", text)
