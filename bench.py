@@ -107,6 +107,60 @@ def roofline(wl, timings, steps, alu_peak=None, wall_s=None):
     return out
 
 
+def exclusive_pass(wl, bbp, torch, device, dev_index, alu_peak, steps=3):
+    """The reproducible roofline figure.  The shipped schedule cuts a batch into slices whose launches overlap in time, so the
+    per-launch durations behind `roofline.frac` are stretched by co-residency.  Here the same inputs go through a SECOND context
+    created with BBP_SLICES=1 (verifier: one lane): no two launches of the dominant kernel overlap, a launch covers the whole batch,
+    and (summed launch time of the dominant kernel per step) is what rocprofv3's exclusive kernel-stats pass shows as well
+    (profiles/README.md).  Results must equal the shipped schedule's byte for byte."""
+    old = os.environ.get("BBP_SLICES")
+    os.environ["BBP_SLICES"] = "1"
+    try:
+        ctx2 = bbp.Context(dev_index)
+    finally:
+        if old is None:
+            os.environ.pop("BBP_SLICES", None)
+        else:
+            os.environ["BBP_SLICES"] = old
+    try:
+        w2 = wl.clone_for(ctx2)
+        if w2 is None:
+            return None
+        s2 = torch.cuda.ExternalStream(ctx2.stream, device=device)
+        with torch.cuda.stream(s2):
+            w2.step(s2.cuda_stream)
+            w2.drain()
+            torch.cuda.synchronize()
+            if os.environ.get("BBP_BENCH_NO_CHECK") != "1" and not wl.same_results(w2):
+                raise SystemExit("PARITY FAILURE: the exclusive (one-slice) schedule and the shipped schedule disagree")
+            ctx2.set_profiling(True)
+            ctx2.last_timings()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                w2.step(s2.cuda_stream)
+            w2.drain()
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t0
+            timings = ctx2.last_timings()
+            ctx2.set_profiling(False)
+        dom = [us for tag, us in timings if tag == wl.dominant_tag]
+        dom_ms = sum(dom) / steps / 1e3
+        achieved = wl.alg_bytes_per_step / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        out = {"frac": achieved / HBM_PEAK_GBPS, "achieved": achieved, "unit": "GB/s", "dominant_ms_per_step": dom_ms, "launches_per_step": len(dom) / steps,
+               "steps": steps, "ms_per_step": wall / steps * 1e3,
+               "how": "second context with BBP_SLICES=1 (verifier: one lane), same inputs, results byte-equal to the shipped schedule's; "
+                      "achieved = algorithmic bytes per step / summed launch time of %s per step" % wl.dominant_kernel}
+        if alu_peak and dom_ms > 0:
+            out["alu_frac"] = wl.row_additions_per_step / (dom_ms * 1e-3) / alu_peak
+        del w2, s2
+        return out
+    finally:
+        import gc
+        torch.cuda.synchronize()
+        gc.collect()
+        ctx2.close()
+
+
 def launch_ranks(args, argv):
     """--gpus N > 1 without a launcher: start N fresh ranks (this process has not touched the GPU), relay rank 0's JSON line."""
     import socket
@@ -191,6 +245,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary verify / msm-stage measurements")
     ap.add_argument("--no-build", action="store_true", help="do not compile anything: fail if the native artefacts are stale")
+    ap.add_argument("--no-exclusive", action="store_true", help="skip the exclusive (one-slice) pass behind roofline.exclusive")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -285,6 +340,10 @@ def main():
                            "backend": backend if world > 1 else "none (single rank: local copy)", "checked": "sample of every rank's block vs the C oracle"}
         del gathered
 
+    exclusive = None
+    if rank == 0 and not STUB and not args.no_exclusive:
+        exclusive = exclusive_pass(wl, bbp, torch, device, dev_index, alu_peak)
+
     also = {}
     if args.workload == "prove" and not args.no_also and not STUB:
         for name, cls in (("verify", VerifyWorkload), ("verify_aggregated", VerifyAggregatedWorkload), ("msm_stage", MsmWorkload)):
@@ -314,6 +373,8 @@ def main():
         }
         if not STUB:
             out["roofline"] = roofline(wl, timings, args.steps, alu_peak, dt)
+            if exclusive:
+                out["roofline"]["exclusive"] = exclusive
         out.update(wl.extra_report(timings))
         if gather_info:
             out["gather"] = gather_info

@@ -110,7 +110,7 @@ def _traffic_from_profiles(key):
     try:
         import json
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[key]
-        return int(t["bytes_per_step"]), t["source"]
+        return int(t["bytes_per_step"]), t["source"] + (" [measured %s]" % t["measured_on"] if t.get("measured_on") else "")
     except Exception:
         return None, None
 
@@ -136,6 +136,11 @@ class _Base:
 
     def drain(self):
         pass
+
+    def clone_for(self, ctx2):
+        """The same inputs on another context of the same device, with outputs of its own (bench.py's exclusive pass); None = this
+        workload has no exclusive form."""
+        return None
 
 
 class StubWorkload(_Base):
@@ -177,6 +182,7 @@ class MsmWorkload(_Base):
         self.alg_bytes_per_step = batch * (terms * 160 + 32 * len(self.shapes))
         self.row_additions_per_step = batch * terms * NAF12_DIGITS
         self.dominant_launches_per_step = len(self.shapes)
+        self.traffic_key = "msm_b%d_n%d" % (batch, items)
         self.config = {"workload": "configs[1]: batch of %d blind-bid proofs, commitment MSMs only (N=%d: %s terms)"
                        % (batch, items, "+".join(str(n) for n, _ in self.shapes)),
                        "batch_per_gpu": batch, "bid_list_len": items, "msm_recoding": "NAF-12", "parallelism": "batch-sharded"}
@@ -184,6 +190,16 @@ class MsmWorkload(_Base):
     def step(self, stream):
         for (n, layout), s, o in zip(self.shapes, self.scal, self.out):
             self.ctx.msm_batch_dev(self.B, n, s.data_ptr(), layout, o.data_ptr(), stream)
+
+    def clone_for(self, ctx2):
+        import copy
+        w = copy.copy(self)
+        w.ctx = ctx2
+        w.out = [self.torch.zeros_like(o) for o in self.out]
+        return w
+
+    def same_results(self, other):
+        return all(bool((a == b).all()) for a, b in zip(self.out, other.out))
 
     def check(self):
         lib = _oracle_lib()
@@ -264,6 +280,16 @@ class ProveWorkload(_Base):
 
     def records(self):
         return bytes(self.out_dev.cpu().numpy().tobytes())
+
+    def clone_for(self, ctx2):
+        import copy
+        w = copy.copy(self)
+        w.ctx = ctx2
+        w.out_dev = self.torch.zeros_like(self.out_dev)
+        return w
+
+    def same_results(self, other):
+        return bool((self.out_dev == other.out_dev).all())
 
     def check(self):
         lib = _oracle_lib()
@@ -352,6 +378,23 @@ class VerifyWorkload(_Base):
         self.config = {"workload": "%sbatch of %d full blind-bid verifications (N=%d), %d corrupted at known indices, %d distinct proofs"
                        % ("configs[3] shard: " if batch == 8192 else "", batch, items, len(self.bad), distinct),
                        "batch_per_gpu": batch, "bid_list_len": items, "parallelism": "batch-sharded, flags gathered to rank 0"}
+
+    def clone_for(self, ctx2):
+        """One verifier lane on the other context: consecutive calls are then ordered one behind the other, no two of their
+        launches overlap."""
+        import copy
+        w = copy.copy(self)
+        w.ctx = ctx2
+        w.lanes = 1
+        w.lane_streams = [self.torch.cuda.ExternalStream(ctx2.verify_stream(0), device=self.in_dev.device)]
+        w.lane_status = [self.torch.full((self.B,), -1, dtype=self.torch.int32, device=self.in_dev.device)]
+        w.status = w.lane_status[0]
+        w.k = 0
+        w.config = dict(self.config)
+        return w
+
+    def same_results(self, other):
+        return bool((self.status == other.status).all())
 
     def _lane(self):
         i = self.k % self.lanes
