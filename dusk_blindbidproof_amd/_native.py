@@ -54,6 +54,7 @@ SIGNATURES = {
     "bbp_batching_stats": (_i32, [_vp, ctypes.POINTER(_u64), ctypes.POINTER(_u64), ctypes.POINTER(_u32)]),
     "bbp_debug_compile_circuit": (_i32, [_u32, ctypes.POINTER(_u32), ctypes.POINTER(_u32)]),
     "bbp_check_health": (_i32, [_vp, ctypes.POINTER(_u32)]),
+    "bbp_debug_corrupt_scratch": (_i32, [_vp]),
     "bbp_debug_challenges": (_i32, [_vp, _u32, _u32, _u32, _vp]),
     "bbp_ubench": (_i32, [_vp, _i32, _u32, _u32, ctypes.POINTER(ctypes.c_double)]),
     "bbp_set_profiling": (_i32, [_vp, _i32]),
@@ -283,6 +284,10 @@ class Context:
         f = ctypes.c_uint32()
         self._check(lib.bbp_check_health(self._h, ctypes.byref(f)))
         return f.value
+
+    def debug_corrupt_scratch(self):
+        """Test hook: the next MSM launch finds an out-of-range entry in its sorted scratch (bbp_debug_corrupt_scratch)."""
+        self._check(lib.bbp_debug_corrupt_scratch(self._h))
 
     def debug_challenges(self, B, N, proof):
         out = (ctypes.c_uint8 * (32 * 32))()

@@ -116,7 +116,13 @@ extern "C" int32_t bbp_msm_batch(bbp_ctx* ctx, uint32_t B, uint32_t n_terms, con
         rc = msm_batch_dev(ctx, B, n_terms, ctx->scal.p, layout, ctx->enc.p, ctx->stream);
         if (rc) return rc;
         BBP_HIP_TRY(ctx, hipMemcpyAsync(out32, ctx->enc.p, (size_t)B * 32, hipMemcpyDeviceToHost, ctx->stream));
+        u32 flags = 0;
+        BBP_HIP_TRY(ctx, hipMemcpyAsync(&flags, ctx->health, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
         BBP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (flags) {  // (see fetch_results in capi_prove.hip)
+            ctx->err = "engine health flags raised: an MSM table gather was out of range (corrupted engine scratch); results are not trustworthy";
+            return BBP_ERR_DEVICE;
+        }
         return BBP_OK;
     });
 }

@@ -288,10 +288,23 @@ static int32_t fetch_results(bbp_ctx* ctx, bbp_ctx::IoSlot& sl, size_t bytes) {
     hipError_t e = hipSetDevice(ctx->device);  // the lock is not held here and nothing has set this thread's device yet (pool workers)
     if (e == hipSuccess) e = wait_event_polling(sl.ev);
     if (e == hipSuccess) e = hipMemcpyAsync(sl.h_out, sl.out.p, bytes, hipMemcpyDeviceToHost, ctx->copy);
+    // ... and the context's health word with them: a call whose kernels (or any earlier call's) had to clamp a table gather reports
+    // BBP_ERR_DEVICE for the whole call instead of handing out results computed from corrupted scratch with status 0
+    if (e == hipSuccess) e = hipMemcpyAsync(sl.h_flag, ctx->health, sizeof(u32), hipMemcpyDeviceToHost, ctx->copy);
     if (e == hipSuccess) e = hipEventRecord(sl.ev_in, ctx->copy);
     if (e == hipSuccess) e = wait_event_polling(sl.ev_in);
     if (e != hipSuccess) {
         api_guard(ctx, [&]() -> int32_t { return ctx->err = std::string("collecting results: ") + hipGetErrorString(e), BBP_ERR_DEVICE; });
+        return BBP_ERR_DEVICE;
+    }
+    if (*sl.h_flag) {
+        const u32 flags = *sl.h_flag;
+        api_guard(ctx, [&]() -> int32_t {
+            char buf[200];
+            snprintf(buf, sizeof buf, "engine health flags %#x: an MSM table gather was out of range and had to be clamped (corrupted engine scratch); "
+                                      "results since then are not trustworthy -- free this context and create a new one", flags);
+            return ctx->err = buf, BBP_ERR_DEVICE;
+        });
         return BBP_ERR_DEVICE;
     }
     return BBP_OK;

@@ -94,6 +94,8 @@ struct bbp_ctx {
     int slices = 3;
     int sort_staged = 3;       // bit 0: generic MSMs, bit 1: the generator-fold pass sort with the scatter staged through LDS (msm.hip k_msm_sort_staged; BBP_SORT_STAGED)
     bool sort_lds_attr = false; // k_msm_sort_staged's dynamic-LDS limit has been raised on this context's device
+    bool sort_lds_attr1 = false;  // ... and that of the generator-fold instance
+    int debug_corrupt = 0;      // bbp_debug_corrupt_scratch: poison the next MSM launch's sorted scratch (tests)
     int fold_half_from = 512;  // MSM launches with at least this many MSMs fold on half a wavefront per MSM (msm.hip k_msm_fold_half; BBP_FOLD_HALF_FROM)
     int tail_round = bbp::FOLD_ROUND;  // first IPA round run on explicit folded generators (BBP_TAIL_ROUND=12 disables)
     int serial_lds = 160 * 1024;  // LDS the one-lane-per-proof opening kernels reserve to keep their CU to themselves (BBP_SERIAL_LDS, 0 = off)
@@ -163,6 +165,7 @@ struct bbp_ctx {
     // k+1 under the MSM stage of call k) also works for bbp_prove_batch / bbp_prove / the UDS server (capi_prove.hip).
     struct IoSlot {
         bbp::DevBuf in, ent, out;
+        uint32_t* h_flag = nullptr;              // pinned: the context's health word as read back with this slot's results
         void *h_out = nullptr, *h_in = nullptr;  // pinned mirrors: results / inputs (a copy from PAGEABLE memory waits for the whole
         size_t h_cap = 0, h_in_cap = 0;          // device to go idle -- measured 87 ms behind a running batch -- a pinned one does not)
         hipEvent_t ev = nullptr, ev_in = nullptr;

@@ -815,10 +815,14 @@ int32_t fold_generators_launch(bbp_ctx* ctx, uint32_t n_proofs, const sc* g_dev,
     const MsmScratch m = msm_scratch_layout(scratch.p, n_work, n_sub, FOLD_W, FOLD_K, FOLD_CLS);
     {
         ScopedEvent ev(ctx, TAG_MSM_SORT, stream);
-        if (ctx->sort_staged & 2)
+        if (ctx->sort_staged & 2) {
+            if (!ctx->sort_lds_attr1) {  // 36 KB static + 32 KB dynamic LDS: above the 64 KB a kernel gets without opting in (per context = per device)
+                BBP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_msm_sort_staged<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sort_cap<1>::V * 4)));
+                ctx->sort_lds_attr1 = true;
+            }
             hipLaunchKernelGGL(k_msm_sort_staged<1>, dim3((u32)n_work), dim3(SORT_T), sort_cap<1>::V * 4, stream, (const u32*)g_dev, (const u32*)h_dev, 2048u, 1u,
                                n_sub, split, m.sorted, m.cursor, (const u32*)nullptr, (const u32*)nullptr, sort_cap<1>::V);
-        else
+        } else
             hipLaunchKernelGGL(k_msm_sort<1>, dim3((u32)n_work), dim3(SORT_T), 0, stream, (const u32*)g_dev, (const u32*)h_dev, 2048u, 1u, n_sub, split,
                                m.sorted, m.cursor, (const u32*)nullptr, (const u32*)nullptr);
         BBP_HIP_TRY(ctx, hipGetLastError());
@@ -852,6 +856,9 @@ __global__ __launch_bounds__(64) void k_encode(const ge* __restrict__ pts, u32 n
     o[1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
 
+// test hook (bbp_debug_corrupt_scratch): what a stray write into the engine's scratch would look like to the accumulate kernel
+__global__ void k_debug_poke(u32* sorted) { sorted[0] = 0x7ffffff0u; }
+
 int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* scalars_dev, const u32* base_idx_dev,
                    ge* out_points_dev, hipStream_t stream, uint32_t n_idx_sets, int scratch_slot, const u32* msm_map_dev,
                    const u32* n_active_dev) {
@@ -884,6 +891,11 @@ int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* sc
         else
             hipLaunchKernelGGL(k_msm_sort<0>, dim3(n_work), dim3(SORT_T), 0, stream, scalars_dev, base_idx_dev, n_terms, n_idx_sets, n_sub, split,
                                m.sorted, m.cursor, msm_map_dev, n_active_dev);
+        BBP_HIP_TRY(ctx, hipGetLastError());
+    }
+    if (ctx->debug_corrupt) {  // bbp_debug_corrupt_scratch: the next MSM launch finds an out-of-range entry in its sorted scratch
+        ctx->debug_corrupt = 0;
+        hipLaunchKernelGGL(k_debug_poke, dim3(1), dim3(1), 0, stream, m.sorted);
         BBP_HIP_TRY(ctx, hipGetLastError());
     }
     {

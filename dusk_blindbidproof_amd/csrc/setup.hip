@@ -174,6 +174,8 @@ static int32_t init_body(int32_t device, bbp_ctx** out) {
     }
     for (int f = 0; f < bbp_ctx::FAMILIES; f++) BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_last[f], hipEventDisableTiming));
     for (auto& sl : ctx->io) {
+        BBP_HIP_TRY(ctx, hipHostMalloc((void**)&sl.h_flag, sizeof(uint32_t), hipHostMallocDefault));
+        *sl.h_flag = 0;
         BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
         BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming));
     }
@@ -275,6 +277,7 @@ extern "C" void bbp_free(bbp_ctx* ctx) {
     for (auto& sl : ctx->io) {
         for (void* p : {sl.in.p, sl.ent.p, sl.out.p})
             if (p) (void)hipFree(p);
+        if (sl.h_flag) (void)hipHostFree(sl.h_flag);
         if (sl.h_out) (void)hipHostFree(sl.h_out);
         if (sl.h_in) (void)hipHostFree(sl.h_in);
         if (sl.ev) (void)hipEventDestroy(sl.ev);
@@ -333,6 +336,16 @@ extern "C" const char* bbp_last_error(const bbp_ctx* ctx) {
 extern "C" void* bbp_context_stream(bbp_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 extern "C" void* bbp_context_copy_stream(bbp_ctx* ctx) { return ctx ? (void*)ctx->copy : nullptr; }
 extern "C" void* bbp_context_verify_stream(bbp_ctx* ctx, uint32_t lane) { return ctx && lane < bbp_ctx::VLANES ? (void*)ctx->vl[lane].stream : nullptr; }
+
+// Test hook: the next MSM launch of this context finds an out-of-range entry in its sorted scratch, as a stray write would leave it.
+extern "C" int32_t bbp_debug_corrupt_scratch(bbp_ctx* ctx) {
+    if (!ctx) return BBP_ERR_BAD_ARG;
+    if (is_pool(ctx)) return bbp_debug_corrupt_scratch(ctx->members[0]);
+    return api_guard(ctx, [&]() -> int32_t {
+        ctx->debug_corrupt = 1;
+        return BBP_OK;
+    });
+}
 
 // Synchronises the device.  *flags: bit 0 = some MSM table gather since bbp_init was out of range and had to be clamped -- the
 // engine's scratch was corrupted and results computed since then may be wrong (never observed; the clamp exists so that such a

@@ -229,8 +229,16 @@ int32_t bbp_batching_stats(bbp_ctx* ctx, uint64_t* n_calls, uint64_t* n_requests
  * barrier can be exercised without a GPU (BBP_FAULT_INJECT=compile in the environment makes the synthesis throw). */
 int32_t bbp_debug_compile_circuit(uint32_t N, uint32_t* n_mul, uint32_t* n_cons);
 
+/* Test hook: poisons the sorted scratch of the context's NEXT MSM launch with an out-of-range entry (what a stray write would leave).
+ * The accumulate kernel clamps the gather (no fault), raises health bit 0, and -- the point of the hook -- the host-pointer call whose
+ * results were fetched next returns BBP_ERR_DEVICE instead of BBP_OK with a wrong proof. */
+int32_t bbp_debug_corrupt_scratch(bbp_ctx* ctx);
+
 /* Engine self-check (synchronises the device).  *flags bit 0: an MSM table gather was out of range since bbp_init and had to be
- * clamped, i.e. engine scratch was corrupted (the one GPU fault of round 1 was such a state); 0 = healthy. */
+ * clamped, i.e. engine scratch was corrupted (the one GPU fault of round 1 was such a state); 0 = healthy.  The flag is
+ * sticky.  Every host-pointer call (bbp_prove[_batch], bbp_verify[_batch][_aggregated], bbp_msm_batch, the asynchronous forms)
+ * reads it back with its results and returns BBP_ERR_DEVICE for the whole call once it is set -- never BBP_OK with results computed
+ * from corrupted scratch; callers of the stream-ordered *_dev entry points poll this function at their own synchronisation points. */
 int32_t bbp_check_health(bbp_ctx* ctx, uint32_t* flags);
 
 /* Parity hook: the 32-scalar challenge block of proof `proof` of the LAST batch call of geometry (B, N):

@@ -202,3 +202,41 @@ def test_null_stream_is_the_callers_default_stream(ctx, oc, bbp):
     ctx.prove_batch_dev(B, N, d_in.data_ptr(), d_ent.data_ptr(), d_out.data_ptr())   # context stream: caller synchronises the device
     torch.cuda.synchronize()
     assert bytes(d_out.cpu().numpy().tobytes()) == ref
+
+
+def test_corrupted_scratch_fails_the_call_instead_of_returning_a_wrong_proof(bbp, ctx, oc):
+    """include/bbp.h "never aborts, never lies": an out-of-range entry in the MSM's sorted scratch (the state behind round 1's one
+    GPU fault; injected here through bbp_debug_corrupt_scratch) is clamped by the accumulate kernel -- no fault -- and raises the
+    context's health bit.  The call whose results are fetched next must come back BBP_ERR_DEVICE as a whole, NOT status 0 with a
+    record computed from garbage; the flag is sticky (every later host-pointer call on that context fails the same way, single
+    calls through the combiner included) and other contexts are unaffected."""
+    N, B = 4, 6
+    ins, ents, vins = _synth_batch(ctx, B, N, seed=31415)
+    exp, est = oc.prove_many(b"".join(ins), b"".join(ents), B, N, threads=4)
+    assert est == [0] * B
+    c = bbp.Context(0)
+    try:
+        out, st = c.prove_batch(B, N, b"".join(ins), b"".join(ents))
+        assert st == [0] * B and out == exp and c.health() == 0
+        c.debug_corrupt_scratch()
+        with pytest.raises(bbp.BbpError) as e:
+            c.prove_batch(B, N, b"".join(ins), b"".join(ents))
+        assert e.value.status == 5 and "health" in str(e.value)
+        assert c.health() == 1
+        with pytest.raises(bbp.BbpError) as e:                       # sticky: the batch API ...
+            c.verify_batch(1, N, exp[:bbp.record_size(N)] + b"".join(vins[0]))
+        assert e.value.status == 5
+        with pytest.raises(bbp.BbpError) as e:                       # ... the single calls through the combiner ...
+            c.prove(ins[0][:224], ins[0][224:224 + 32 * N], 0, ents[0])
+        assert e.value.status == 5
+        assert c.verify(exp[:bbp.record_size(N)], *vins[0]) == 5
+        import random
+        rnd = random.Random(1)
+        sc = b"".join(rnd.getrandbits(252).to_bytes(32, "little") for _ in range(9))
+        with pytest.raises(bbp.BbpError) as e:                       # ... and the MSM hook
+            c.msm_batch(1, 9, sc, bbp.LAYOUT_BLIND_G_H)
+        assert e.value.status == 5
+    finally:
+        c.close()
+    out, st = ctx.prove_batch(B, N, b"".join(ins), b"".join(ents))   # the session's context never saw it
+    assert st == [0] * B and out == exp and ctx.health() == 0
