@@ -363,9 +363,12 @@ class VerifyWorkload(_Base):
         self.rows = rows
         self.in_dev = _to_dev(torch, device, b"".join(bytes(r) for r in rows))
         self.ent_dev = _to_dev(torch, device, hashlib.shake_256(b"verifier-entropy%d" % seed).digest(32 * batch))
-        # consecutive steps alternate between the verifier's two lanes (include/bbp.h bbp_context_verify_stream): the front end
-        # of one call runs under the generator MSM of the other; BBP_BENCH_VERIFY_LANES=1 keeps every step on one stream
-        self.lanes = 1 if os.environ.get("BBP_BENCH_VERIFY_LANES") == "1" else 2
+        # consecutive steps rotate over the verifier's lanes (include/bbp.h bbp_context_verify_stream): the front end of one call
+        # runs under the generator MSM of another; BBP_BENCH_VERIFY_LANES=n uses only n of them (1: every step on one stream)
+        avail = 0
+        while avail < 8 and ctx.verify_stream(avail):
+            avail += 1
+        self.lanes = max(1, min(avail, int(os.environ.get("BBP_BENCH_VERIFY_LANES", avail))))
         self.lane_streams = [torch.cuda.ExternalStream(ctx.verify_stream(i), device=device) for i in range(self.lanes)]
         self.lane_status = [torch.full((batch,), -1, dtype=torch.int32, device=device) for _ in range(self.lanes)]
         self.status = self.lane_status[0]

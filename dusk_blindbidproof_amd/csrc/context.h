@@ -114,7 +114,15 @@ struct bbp_ctx {
     hipEvent_t ev_open[PROVE_BUFS] = {nullptr, nullptr, nullptr}, ev_done[PROVE_BUFS] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_entry[PROVE_BUFS] = {nullptr, nullptr, nullptr};  // caller's stream at entry of a prove call: out_dev is not written before it
     bool ev_done_valid[PROVE_BUFS] = {false, false, false}, ev_open_valid[PROVE_BUFS] = {false, false, false};
-    int verify_overlap = 1;                              // BBP_VERIFY_OVERLAP
+    int verify_overlap = 0;                              // BBP_VERIFY_OVERLAP=1: the variable-base kernels on a side stream (round 3: measured slower with chained accumulates, 6.8 vs 6.3 ms per 1024)
+    // The verifier lanes' MSM accumulate launches are chained by events so that no two of them are co-resident: each then runs beside
+    // the other lanes' thin front-end kernels only, and the lanes settle out of phase (BBP_VERIFY_SERIAL_ACC=0: free-running lanes
+    // lock in phase -- all thin chains together, then all accumulates together, the machine idling in between)
+    int verify_serial_acc = 1;
+    static constexpr int VACC_RING = 4;
+    hipEvent_t ev_vacc[VACC_RING] = {};
+    uint32_t vacc_seq = 0;
+    bool vacc_valid = false;
     uint32_t verify_group = 0;  // BBP_VERIFY_AGGREGATE=G: bbp_verify / bbp_verify_batch (host API, hence the UDS server) check proofs in
                                 // groups of G with per-proof fallback -- same statuses, 2-3x the rate; 0 = one MSM per proof like the reference
     uint32_t seq_at_last_verify = 0;                     // prover call counter seen by the last verification (interleaving test)
@@ -127,15 +135,18 @@ struct bbp_ctx {
     // two families with disjoint scratch: 0 = prover, MSM hook, witness, setup read-backs; 1 = verifier (its own batch buffer,
     // misc scratch and MSM scratch slot VERIFY_SLOT) -- a verification issued on another stream than a prove call is NOT ordered
     // behind it and overlaps its heavy stage on the device
-    static constexpr int FAMILIES = 3;  // prover | verifier lane 0 | verifier lane 1
-    hipStream_t last_stream[FAMILIES] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_last[FAMILIES] = {nullptr, nullptr, nullptr};
-    bool ev_last_valid[FAMILIES] = {false, false, false};
+    static constexpr int VLANES = 2;             // (the code takes any number; three lanes measured 8-10 % SLOWER than two, see below)
+    static constexpr int FAMILIES = 1 + VLANES;  // prover | one per verifier lane
+    hipStream_t last_stream[FAMILIES] = {};
+    hipEvent_t ev_last[FAMILIES] = {};
+    bool ev_last_valid[FAMILIES] = {};
     // Two verifier LANES, each with everything a verification call touches (batch buffer, scratch, MSM scratch slot, aggregation
     // buffers, a stream): two calls on the two lanes share nothing, so the front end of one (parse, transcripts, powers, flatten,
     // scalars: latency-bound) runs under the MSM of the other.  The host-pointer API alternates lanes with its staging slots;
     // device-API callers pick a lane by passing that lane's stream (bbp_context_verify_stream), any other stream is lane 0.
-    static constexpr int VLANES = 2;
+    // Two lanes.  A 1024-proof call is a chain of ~10 ms of kernels of which only the 4 ms MSM accumulate fills the machine; a
+    // third chain in flight was tried in round 3 (VLANES = 3) and lost: 7.2 instead of 6.3-6.5 ms per call -- the front-end kernels of
+    // two other calls slow each other and the accumulate more than the extra overlap gives back.
     struct VLane {
         hipStream_t stream = nullptr;
         bbp::DevBuf misc, agg, agg_io;
@@ -237,12 +248,19 @@ inline unsigned lds_token(const bbp_ctx* ctx) { return ctx->serial_lds >= 160 * 
 
 // One-lane-per-item serial kernels that run beside the MSM stage ask for (nearly) a whole CU's LDS so that nothing else is placed
 // on their CU (prover.hip "Serial waves get their own CUs"): raise the kernel's dynamic-LDS limit once per kernel.
-inline int32_t serial_lds_bytes(bbp_ctx* ctx, const void* kernel) {
+inline int32_t serial_lds_bytes(bbp_ctx* ctx, const void* kernel, unsigned* dyn_bytes = nullptr) {
+    if (dyn_bytes) *dyn_bytes = 0;
     if (ctx->serial_lds <= 0) return BBP_OK;
     if (!ctx->serial_attr.count(kernel)) {
-        BBP_HIP_TRY(ctx, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->serial_lds));
-        ctx->serial_attr[kernel] = 1;
+        // the reservation is dynamic LDS on top of whatever the kernel declares statically: together they must fit the CU's 160 KB
+        hipFuncAttributes fa;
+        BBP_HIP_TRY(ctx, hipFuncGetAttributes(&fa, kernel));
+        int dyn = ctx->serial_lds - (int)fa.sharedSizeBytes;
+        if (dyn < 0) dyn = 0;
+        BBP_HIP_TRY(ctx, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
+        ctx->serial_attr[kernel] = dyn;
     }
+    if (dyn_bytes) *dyn_bytes = (unsigned)ctx->serial_attr[kernel];
     return BBP_OK;
 }
 
@@ -337,9 +355,10 @@ int32_t pool_reject(bbp_ctx* pool, const char* what);  // BBP_ERR_BAD_ARG + mess
 // base_idx_dev holds n_idx_sets lists of n_terms indices; MSM number i uses list (i % n_idx_sets)
 // msm_map_dev / n_active_dev (both or neither): a device-sized launch -- n_msm is the upper bound, *n_active_dev MSMs exist and MSM j
 // takes its scalars from row msm_map_dev[j]
+// chain_acc: the accumulate launch waits for the previous chained accumulate launch of this context (verifier lanes, see verify_serial_acc)
 int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* scalars_dev, const u32* base_idx_dev,
                    ge* out_points_dev, hipStream_t stream, uint32_t n_idx_sets = 1, int scratch_slot = 0, const u32* msm_map_dev = nullptr,
-                   const u32* n_active_dev = nullptr);
+                   const u32* n_active_dev = nullptr, bool chain_acc = false);
 int32_t fold_generators_launch(bbp_ctx* ctx, uint32_t n_proofs, const sc* g_dev, const sc* h_dev, ge* out_dev, hipStream_t stream,
                                int scratch_slot);
 int32_t encode_launch(bbp_ctx* ctx, uint32_t n, const ge* pts_dev, uint8_t* out32_dev, hipStream_t stream);

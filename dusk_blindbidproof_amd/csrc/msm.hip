@@ -861,7 +861,7 @@ __global__ void k_debug_poke(u32* sorted) { sorted[0] = 0x7ffffff0u; }
 
 int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* scalars_dev, const u32* base_idx_dev,
                    ge* out_points_dev, hipStream_t stream, uint32_t n_idx_sets, int scratch_slot, const u32* msm_map_dev,
-                   const u32* n_active_dev) {
+                   const u32* n_active_dev, bool chain_acc) {
     if (n_msm == 0) return BBP_OK;
     if (n_terms == 0 || n_terms > 65535u) {
         ctx->err = "msm_launch: n_terms out of range";
@@ -898,11 +898,20 @@ int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* sc
         hipLaunchKernelGGL(k_debug_poke, dim3(1), dim3(1), 0, stream, m.sorted);
         BBP_HIP_TRY(ctx, hipGetLastError());
     }
+    chain_acc = chain_acc && ctx->verify_serial_acc;
+    if (chain_acc && ctx->vacc_valid)  // (the sort above ran beside the previous accumulate; this one starts when that one is through)
+        BBP_HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->ev_vacc[ctx->vacc_seq % bbp_ctx::VACC_RING], 0));
     {
         ScopedEvent ev(ctx, TAG_MSM, stream);
         hipLaunchKernelGGL(k_msm_acc<0>, dim3(n_work * ACC_WGS), dim3(ACC_WG), 0, stream, ctx->ptable, m.sorted, m.cursor, n_sub, m.bsum, m.psum,
                            split > 1 ? m.tmp : out_points_dev, n_active_dev, ctx->health);
         BBP_HIP_TRY(ctx, hipGetLastError());
+    }
+    static const bool chain_after_fold = getenv("BBP_VERIFY_CHAIN_AFTER_FOLD") && atoi(getenv("BBP_VERIFY_CHAIN_AFTER_FOLD"));
+    if (chain_acc && !chain_after_fold) {
+        ctx->vacc_seq++;
+        BBP_HIP_TRY(ctx, hipEventRecord(ctx->ev_vacc[ctx->vacc_seq % bbp_ctx::VACC_RING], stream));
+        ctx->vacc_valid = true;
     }
     ScopedEvent evf(ctx, TAG_MSM_FOLD, stream);
     // many MSMs: the fold on half a wavefront per MSM (fewer wave-instructions); few: the 128-lane fold (shorter chain).  BBP_FOLD_HALF_FROM
@@ -912,6 +921,11 @@ int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* sc
     else
         hipLaunchKernelGGL(k_msm_fold<0>, dim3(n_work), dim3(MSM_T), 0, stream, m.cursor, m.bsum, m.psum, split > 1 ? m.tmp : out_points_dev, n_active_dev);
     BBP_HIP_TRY(ctx, hipGetLastError());
+    if (chain_acc && chain_after_fold) {  // experiment: the next lane's accumulate waits for this lane's fold as well (222 registers: it crawls beside two accumulate waves)
+        ctx->vacc_seq++;
+        BBP_HIP_TRY(ctx, hipEventRecord(ctx->ev_vacc[ctx->vacc_seq % bbp_ctx::VACC_RING], stream));
+        ctx->vacc_valid = true;
+    }
     if (split > 1) {
         hipLaunchKernelGGL(k_msm_reduce, dim3((n_msm + 63) / 64), dim3(64), lds_token(ctx), stream, n_msm, split, 1u, m.tmp, out_points_dev);
         BBP_HIP_TRY(ctx, hipGetLastError());

@@ -181,6 +181,8 @@ static int32_t init_body(int32_t device, bbp_ctx** out) {
     }
     BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming));
     if (const char* e = getenv("BBP_VERIFY_OVERLAP")) ctx->verify_overlap = atoi(e) != 0;
+    if (const char* e = getenv("BBP_VERIFY_SERIAL_ACC")) ctx->verify_serial_acc = atoi(e) != 0;
+    for (auto& e : ctx->ev_vacc) BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (const char* e = getenv("BBP_VERIFY_AGGREGATE")) ctx->verify_group = atoi(e) > 1 ? (uint32_t)atoi(e) : 0u;
     if (const char* e = getenv("BBP_DUAL_OPEN_BELOW")) ctx->dual_open_below = atoi(e);
     if (const char* e = getenv("BBP_ROTATE_BELOW")) ctx->rotate_below = atoi(e);
@@ -261,8 +263,13 @@ extern "C" void bbp_free(bbp_ctx* ctx) {
     }
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    void* ptrs[] = {ctx->gens, ctx->ptable, ctx->btab, ctx->slice_fold[0].p, ctx->slice_fold[1].p, ctx->slice_fold[2].p, ctx->slice_fold[3].p,
-                    ctx->slice_vtab[0].p, ctx->slice_vtab[1].p, ctx->slice_vtab[2].p, ctx->slice_vtab[3].p, ctx->comb, ctx->mimc_c, ctx->scal.p, ctx->idx.p, ctx->sorted.p, ctx->pts.p, ctx->enc.p, ctx->batch[0].p, ctx->io_in.p, ctx->io_out.p, ctx->io_ent.p, ctx->raw[0].p, ctx->raw[1].p, ctx->batch[1].p, ctx->batch[2].p, ctx->batch[3].p, ctx->batch[4].p, ctx->slice_sorted[5].p, ctx->slice_pts[5].p, ctx->slice_sorted[1].p, ctx->slice_sorted[2].p, ctx->slice_sorted[3].p, ctx->slice_pts[1].p, ctx->slice_pts[2].p, ctx->slice_pts[3].p, ctx->slice_sorted[4].p, ctx->slice_pts[4].p};
+    std::vector<void*> ptrs = {ctx->gens, ctx->ptable, ctx->btab, ctx->comb, ctx->mimc_c, ctx->scal.p, ctx->idx.p, ctx->sorted.p, ctx->pts.p, ctx->enc.p,
+                               ctx->io_in.p, ctx->io_out.p, ctx->io_ent.p, ctx->raw[0].p, ctx->raw[1].p};
+    for (auto& b : ctx->batch) ptrs.push_back(b.p);
+    for (auto& b : ctx->slice_sorted) ptrs.push_back(b.p);
+    for (auto& b : ctx->slice_pts) ptrs.push_back(b.p);
+    for (auto& b : ctx->slice_fold) ptrs.push_back(b.p);
+    for (auto& b : ctx->slice_vtab) ptrs.push_back(b.p);
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& kv : ctx->circuits) {  // compiled circuits (one per list length used)
@@ -284,6 +291,8 @@ extern "C" void bbp_free(bbp_ctx* ctx) {
         if (sl.ev_in) (void)hipEventDestroy(sl.ev_in);
     }
     if (ctx->health) (void)hipFree(ctx->health);
+    for (auto& e : ctx->ev_vacc)
+        if (e) (void)hipEventDestroy(e);
     for (auto& L : ctx->vl) {
         for (void* p : {L.misc.p, L.agg.p, L.agg_io.p, (void*)L.agg_count})
             if (p) (void)hipFree(p);

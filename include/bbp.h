@@ -104,9 +104,9 @@ void* bbp_context_stream(bbp_ctx* ctx);
  * bbp_prepare_bids_dev) while the first one carries prove / verify calls: same reason as above -- created at bbp_init beside
  * the engine's streams, it does not share a hardware queue with them. */
 void* bbp_context_copy_stream(bbp_ctx* ctx);
-/* The verifier has two independent lanes (own scratch each): calls issued on the stream of lane 0 and of lane 1 (lane < 2) overlap
- * on the device -- the latency-bound front end of one runs under the MSM of the other -- instead of being ordered one behind the
- * other like calls on any other pair of streams.  The host-pointer verify calls alternate lanes by themselves. */
+/* The verifier has two independent lanes (own scratch each): calls issued on the streams of different lanes (lane < 2; NULL beyond)
+ * overlap on the device -- the latency-bound front end of one runs under the MSM of another -- instead of being ordered one behind
+ * the other like calls on any other pair of streams.  The host-pointer verify calls rotate over the lanes by themselves. */
 void* bbp_context_verify_stream(bbp_ctx* ctx, uint32_t lane);
 void bbp_free(bbp_ctx* ctx);
 const char* bbp_last_error(const bbp_ctx* ctx);
