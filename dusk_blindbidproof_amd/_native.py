@@ -55,6 +55,7 @@ SIGNATURES = {
     "bbp_debug_compile_circuit": (_i32, [_u32, ctypes.POINTER(_u32), ctypes.POINTER(_u32)]),
     "bbp_check_health": (_i32, [_vp, ctypes.POINTER(_u32)]),
     "bbp_debug_corrupt_scratch": (_i32, [_vp]),
+    "bbp_describe": (_i32, [_vp, _vp, _u32]),
     "bbp_debug_challenges": (_i32, [_vp, _u32, _u32, _u32, _vp]),
     "bbp_ubench": (_i32, [_vp, _i32, _u32, _u32, ctypes.POINTER(ctypes.c_double)]),
     "bbp_set_profiling": (_i32, [_vp, _i32]),
@@ -284,6 +285,12 @@ class Context:
         f = ctypes.c_uint32()
         self._check(lib.bbp_check_health(self._h, ctypes.byref(f)))
         return f.value
+
+    def describe(self):
+        """Text report of the device and configuration; lines starting with WARNING: name conditions that cost throughput."""
+        buf = ctypes.create_string_buffer(8192)
+        self._check(lib.bbp_describe(self._h, buf, len(buf)))
+        return buf.value.decode()
 
     def debug_corrupt_scratch(self):
         """Test hook: the next MSM launch finds an out-of-range entry in its sorted scratch (bbp_debug_corrupt_scratch)."""

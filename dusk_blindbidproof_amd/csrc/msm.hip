@@ -7,17 +7,23 @@
 //
 // The table holds EVERY power-of-two multiple 2^b * P_i (b = 0..255) of every generator as a 128-byte row of ready-to-use
 // limbs, so a scalar can be recoded in width-12 non-adjacent form: odd digits |d| < 2048 at arbitrary bit positions, one
-// non-zero digit per 13 bits on average (19.5 per scalar instead of the 24 of aligned 11-bit windows), 1024 buckets, and
+// non-zero digit per 13 bits on average (19.85 per scalar instead of the 24 of aligned 11-bit windows), 1024 buckets, and
 // no doublings anywhere.  The hot loop is instruction-issue bound (measured: serving all rows from cache changes its time
-// by 7 %), so fewer additions and no unpacking are what count; the generators' 134 MB of rows (275 MB with the padded-range and merged bases) are HBM/MALL resident.
+// by 4 %), so fewer additions and no unpacking are what count; the generators' 134 MB of rows (275 MB with the padded-range and merged bases) are HBM/MALL resident.
 //
-// One workgroup owns one MSM, in two kernels (k_msm_sort: 1024 thin lanes, k_msm_acc: 128 fat lanes):
-//   A. NAF digits of every scalar -> LDS histogram over bucket (|d| + 1) / 2
-//   B. exclusive scan -> bucket offsets
-//   C. counting-sort scatter of (row index, sign) into the MSM's HBM scratch slice; bucket end offsets to HBM
-//   D1. the sorted entry array is cut into 128 equal chunks, one per lane: mixed additions of table rows into bucket sums
-//   D2. running-sum fold over the lane's 8 buckets
-//   E. cross-lane fold (shuffles): W = sum_k k S_k and S = sum_k S_k; result = sum_k (2k - 1) S_k = 2 W - S
+// One MSM = one workgroup in each of THREE kernels:
+//   k_msm_sort[_staged]  (1024 thin lanes)
+//     A. NAF digits of every scalar -> LDS histogram over bucket (|d| + 1) / 2
+//     B. exclusive scan -> bucket offsets
+//     C. counting-sort scatter of (row index, sign) into the MSM's HBM scratch slice (staged through an LDS image and written out
+//        as full lines for MSMs of at most 3000 terms); bucket end offsets to HBM
+//   k_msm_acc            (256 fat lanes, 156 registers, two waves per SIMD)
+//     D1. the sorted entry array is cut into 256 equal chunks, one per lane: mixed additions of gathered table rows into bucket
+//         sums (HBM); a chunk that starts inside a bucket parks its leading partial sum
+//   k_msm_fold_half / k_msm_fold  (half a wavefront per MSM for launches of >= 512 MSMs, else 128 lanes)
+//     P.  chunk-leading partials into their buckets
+//     D2. running-sum fold over the lane's buckets
+//     E.  cross-lane fold (shuffles): W = sum_k k S_k and S = sum_k S_k; result = sum_k (2k - 1) S_k = 2 W - S
 #include "context.h"
 
 namespace bbp {

@@ -346,6 +346,48 @@ extern "C" void* bbp_context_stream(bbp_ctx* ctx) { return ctx ? (void*)ctx->str
 extern "C" void* bbp_context_copy_stream(bbp_ctx* ctx) { return ctx ? (void*)ctx->copy : nullptr; }
 extern "C" void* bbp_context_verify_stream(bbp_ctx* ctx, uint32_t lane) { return ctx && lane < bbp_ctx::VLANES ? (void*)ctx->vl[lane].stream : nullptr; }
 
+// What this context runs on and how it is set up, as text; the conditions that are known to cost throughput silently are called
+// out as WARNING lines (the server logs the report at start-up).
+extern "C" int32_t bbp_describe(bbp_ctx* ctx, char* buf, uint32_t cap) {
+    if (!ctx || !buf || cap == 0) return BBP_ERR_BAD_ARG;
+    buf[0] = 0;
+    if (is_pool(ctx)) {
+        uint32_t off = (uint32_t)snprintf(buf, cap, "device pool of %zu member context(s)\n", ctx->members.size());
+        for (size_t i = 0; i < ctx->members.size() && off + 1 < cap; i++) {
+            off += (uint32_t)snprintf(buf + off, cap - off, "member %zu: ", i);
+            if (off + 1 >= cap) break;
+            if (int32_t rc = bbp_describe(ctx->members[i], buf + off, cap - off)) return rc;
+            off += (uint32_t)strlen(buf + off);
+        }
+        return BBP_OK;
+    }
+    return api_guard(ctx, [&]() -> int32_t {
+        BBP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+        hipDeviceProp_t prop;
+        BBP_HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
+        size_t free_b = 0, total_b = 0;
+        BBP_HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+        const char* hwq = getenv("GPU_MAX_HW_QUEUES");
+        uint32_t off = (uint32_t)snprintf(buf, cap,
+                                          "device %d: %s (%s), %d CUs, %.0f MHz, %.1f of %.1f GiB free; prover: %d heavy-stage slices, tail from round %d, "
+                                          "cooperative rng below %d proofs; verifier: %d lanes, accumulates %s, aggregate groups of %u%s\n",
+                                          ctx->device, prop.name, prop.gcnArchName, prop.multiProcessorCount, prop.clockRate / 1e3, free_b / 1073741824.0,
+                                          total_b / 1073741824.0, ctx->slices, ctx->tail_round, ctx->rng_coop_below, (int)bbp_ctx::VLANES,
+                                          ctx->verify_serial_acc ? "chained" : "free-running", ctx->verify_group, ctx->verify_group ? "" : " (off)");
+        // The engine keeps four streams busy during a prove call (caller's, opening stage, two more slices) and up to three more for
+        // verification: HIP's default of four hardware queues makes two of them share one and serialise (measured 84.5 vs 61.6 ms per
+        // batch).  The variable is read when the HIP runtime initialises, i.e. possibly long before bbp_init.
+        if ((!hwq || atoi(hwq) < 8) && off + 1 < cap)
+            off += (uint32_t)snprintf(buf + off, cap - off,
+                                      "WARNING: GPU_MAX_HW_QUEUES is %s: export GPU_MAX_HW_QUEUES=8 before the process first touches HIP, or streams of this "
+                                      "context may share a hardware queue and serialise (up to ~30 %% slower batches)\n",
+                                      hwq ? hwq : "not set");
+        if (free_b < ((size_t)6 << 30) && off + 1 < cap)
+            off += (uint32_t)snprintf(buf + off, cap - off, "WARNING: less than 6 GiB of device memory free: a 1024-proof batch needs ~14 GiB of scratch\n");
+        return BBP_OK;
+    });
+}
+
 // Test hook: the next MSM launch of this context finds an out-of-range entry in its sorted scratch, as a stray write would leave it.
 extern "C" int32_t bbp_debug_corrupt_scratch(bbp_ctx* ctx) {
     if (!ctx) return BBP_ERR_BAD_ARG;

@@ -86,6 +86,7 @@ struct Engine {
     decltype(&bbp_batching_stats) batching_stats = nullptr;
     decltype(&bbp_check_health) check_health = nullptr;
     decltype(&bbp_reserve) reserve = nullptr;
+    decltype(&bbp_describe) describe = nullptr;  // optional
     bool load(const char* path, std::string* why) {
         so = dlopen(path, RTLD_NOW | RTLD_LOCAL);
         if (!so) return *why = dlerror(), false;
@@ -106,6 +107,7 @@ struct Engine {
         batching_stats = (decltype(batching_stats))sym("bbp_batching_stats");
         check_health = (decltype(check_health))sym("bbp_check_health");
         reserve = (decltype(reserve))sym("bbp_reserve");
+        describe = (decltype(describe))dlsym(so, "bbp_describe");
         return why->empty();
     }
 };
@@ -589,6 +591,11 @@ int main(int argc, char** argv) {
         }
         g_eng.n_devices = devices.size();
         g_eng.set_batching(g_eng.ctx, window_us, max_batch);
+        if (g_eng.describe) {  // what the engine runs on; its WARNING lines (hardware queues, memory) at warn level
+            static char report[8192];
+            if (g_eng.describe(g_eng.ctx, report, sizeof report) == BBP_OK)
+                for (char* ln = strtok(report, "\n"); ln; ln = strtok(nullptr, "\n")) logf(strncmp(ln, "WARNING", 7) == 0 ? 1 : 2, "engine: %s", ln);
+        }
         for (int32_t n : reserve_items) {
             const int32_t rr = g_eng.reserve(g_eng.ctx, max_batch, (uint32_t)n);
             if (rr != BBP_OK) logf(1, "--reserve %d: engine status %d: %s (buffers will grow on demand)", n, rr, g_eng.last_error(g_eng.ctx));

@@ -229,6 +229,11 @@ int32_t bbp_batching_stats(bbp_ctx* ctx, uint64_t* n_calls, uint64_t* n_requests
  * barrier can be exercised without a GPU (BBP_FAULT_INJECT=compile in the environment makes the synthesis throw). */
 int32_t bbp_debug_compile_circuit(uint32_t N, uint32_t* n_mul, uint32_t* n_cons);
 
+/* Diagnostics: a short text report of what the context (every member of a pool) runs on and how it is configured -- device, free
+ * memory, scheduling knobs -- into buf (NUL-terminated, truncated to cap).  Conditions known to cost throughput silently are
+ * reported as lines starting with "WARNING:" (today: GPU_MAX_HW_QUEUES below 8 in the environment, little free device memory). */
+int32_t bbp_describe(bbp_ctx* ctx, char* buf, uint32_t cap);
+
 /* Test hook: poisons the sorted scratch of the context's NEXT MSM launch with an out-of-range entry (what a stray write would leave).
  * The accumulate kernel clamps the gather (no fault), raises health bit 0, and -- the point of the hook -- the host-pointer call whose
  * results were fetched next returns BBP_ERR_DEVICE instead of BBP_OK with a wrong proof. */

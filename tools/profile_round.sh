@@ -36,6 +36,12 @@ pmc vwrite WRITE_SIZE --workload verify --batch 8192
 python3 $REPO/tools/pmc_aggregate.py "$OUT/vfetch" "$OUT/vwrite" --only-grid $((8192 * 256)) --traffic-json "$OUT/traffic.json" verify_b8192_n8 $PMC_STEPS \
   "profiles/${TAG}_verify8192_rocprofv3_pmc_hbm.csv (rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py --workload verify --batch 8192 --steps 1 --warmup 1; only the 8192-workgroup accumulate launches are counted)" \
   > "$OUT/${TAG}_verify8192_rocprofv3_pmc_hbm.csv"
+# 3b. the same at 1024 verifications per call (what the default bench line's also.verify runs)
+pmc v1fetch FETCH_SIZE --workload verify --batch 1024
+pmc v1write WRITE_SIZE --workload verify --batch 1024
+python3 $REPO/tools/pmc_aggregate.py "$OUT/v1fetch" "$OUT/v1write" --only-grid $((1024 * 256)) --traffic-json "$OUT/traffic.json" verify_b1024_n8 $PMC_STEPS \
+  "profiles/${TAG}_verify1024_rocprofv3_pmc_hbm.csv (rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py --workload verify --batch 1024 --steps 1 --warmup 1; only the 1024-workgroup accumulate launches are counted)" \
+  > "$OUT/${TAG}_verify1024_rocprofv3_pmc_hbm.csv"
 # 4. configs[1]: commitment MSMs only
 stats msm bench_msm_under_rocprof.json --workload msm --steps 5 --warmup 2
 pmc mfetch FETCH_SIZE --workload msm
