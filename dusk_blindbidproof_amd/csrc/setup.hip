@@ -250,9 +250,10 @@ static int32_t init_body(int32_t device, bbp_ctx** out) {
 extern "C" void bbp_free(bbp_ctx* ctx) {
     if (!ctx) return;
     if (is_pool(ctx)) {  // a pool owns its members and its combiner, no device state
+        delete static_cast<Combiner*>(ctx->combiner);  // FIRST: its threads run what is still queued on the members, then leave
+        ctx->combiner = nullptr;
         for (bbp_ctx* m : ctx->members) bbp_free(m);
         ctx->members.clear();
-        delete static_cast<Combiner*>(ctx->combiner);
         delete ctx;
         return;
     }
@@ -261,6 +262,10 @@ extern "C" void bbp_free(bbp_ctx* ctx) {
         delete ctx;
         return;
     }
+    // FIRST the combiner: its threads run whatever asynchronous requests are still queued (their callbacks fire) and leave; only then
+    // is it safe to take the device state away
+    delete static_cast<Combiner*>(ctx->combiner);
+    ctx->combiner = nullptr;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     std::vector<void*> ptrs = {ctx->gens, ctx->ptable, ctx->btab, ctx->comb, ctx->mimc_c, ctx->scal.p, ctx->idx.p, ctx->sorted.p, ctx->pts.p, ctx->enc.p,
@@ -303,8 +308,6 @@ extern "C" void bbp_free(bbp_ctx* ctx) {
     for (auto& kv : ctx->layout_idx)
         if (kv.second) (void)hipFree(kv.second);
     ctx->layout_idx.clear();
-    delete static_cast<Combiner*>(ctx->combiner);
-    ctx->combiner = nullptr;
     for (int i = 0; i < bbp_ctx::PROVE_BUFS; i++) {
         if (ctx->ev_entry[i]) (void)hipEventDestroy(ctx->ev_entry[i]);
         if (ctx->ev_open[i]) (void)hipEventDestroy(ctx->ev_open[i]);

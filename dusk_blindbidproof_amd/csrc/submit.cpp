@@ -154,13 +154,12 @@ void Combiner::thread_main(int kind) {
         L.idle++;
         L.cv_work.wait(lk, [&] { return stop_ || !q_.empty(); });
         L.idle--;
-        if (stop_) return;
+        if (q_.empty()) return;  // (only when stopping: requests still queued at that moment are run first -- every callback fires, every waiter returns)
         // Optional window: give concurrent callers a moment to join this batch.
         if (window_us_) {
             const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(window_us_);
             while (!stop_ && q_.size() < max_batch_ && wait_until_steady(cv_window_, lk, deadline) != std::cv_status::timeout) {
             }
-            if (stop_) return;
             if (q_.empty()) continue;  // another thread took everything meanwhile
         }
         // reserve the least-loaded target now (under the lock), so that two threads never count on the same idle device
@@ -194,9 +193,8 @@ void Combiner::thread_main(int kind) {
                 wait_until_steady(cv_window_, lk, tick);
                 if (q_.size() == before || std::chrono::steady_clock::now() >= quiet_cap) break;
             }
-            if (stop_ || q_.empty()) {
+            if (q_.empty()) {
                 targets_[ti].running[kind]--;
-                if (stop_) return;
                 continue;
             }
         }

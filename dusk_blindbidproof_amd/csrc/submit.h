@@ -63,7 +63,7 @@ class Combiner {
     // (thread creation failed): nothing was queued, the hook will not fire
     bool submit_async(bbp_ctx* ctx, Request* r);
     Combiner() = default;
-    ~Combiner();  // stops and joins the threads; no request may be outstanding (bbp_free must not race with calls)
+    ~Combiner();  // runs whatever is still queued (every callback fires, every waiter returns), then joins the threads
     Combiner(const Combiner&) = delete;
     Combiner& operator=(const Combiner&) = delete;
     // Device pool (pool.cpp): one combiner in front of several contexts (one per GPU).  A leader reserves the target with the

@@ -15,7 +15,8 @@
  * number of host threads: each entry point takes the context's lock, and concurrent bbp_prove / bbp_verify calls are coalesced
  * into batch calls on the device (group commit: whatever queued up while the previous batch ran goes out as the next batch), so
  * N concurrent single proofs cost about one batch of N, not N times one.  bbp_last_error is per calling thread.
- * bbp_free must not race with other calls on the same context.
+ * bbp_free must not race with other calls on the same context; asynchronous requests still queued when it is called are run first
+ * (their callbacks fire before bbp_free returns).
  *
  * Several GPUs: bbp_init_all / bbp_pool_init return a POOL handle -- one context per GPU behind the same bbp_ctx* type -- that the
  * host-pointer entry points accept like a context: the reference's worker threads keep calling bbp_prove / bbp_verify on ONE

@@ -103,4 +103,36 @@ static int scenario(int n_targets) {
     return (wrong.load() || bad || reqs != 48 * 40 || per_target_sum != reqs || max_inside > 2 || biggest > ctxs[0].max_batch || idle_targets) ? 1 : 0;
 }
 
-int main() { return scenario(1) | scenario(3); }
+// destruction with asynchronous requests still queued: the combiner runs them first, every completion hook fires exactly once
+static std::atomic<int> g_hooks{0}, g_hook_bad{0};
+static void hook(bbp::Request* r) {
+    if (r->status != 0 || r->out[0] != r->own_in[0]) g_hook_bad++;
+    g_hooks++;
+    delete[] r->out;
+    delete r;
+}
+static int scenario_drain() {
+    bbp_ctx ctx;
+    const int n = 300;
+    {
+        bbp::Combiner comb;
+        comb.configure(2000, ctx.max_batch);  // a long window: most requests are still queued when the destructor runs
+        comb.set_stagger(500);
+        for (int i = 0; i < n; i++) {
+            bbp::Request* r = new bbp::Request();
+            const uint32_t N = 3;
+            r->own_in.assign(7 * 32 + 32 * N + 8, (uint8_t)i);
+            r->kind = 0;
+            r->N = N;
+            r->in = r->own_in.data();
+            r->in_len = r->own_in.size();
+            r->out = new uint8_t[1121 + 32 * (4 + N)];
+            r->on_done = hook;
+            if (!comb.submit_async(&ctx, r)) return 1;
+        }
+    }  // ~Combiner
+    printf("drain: %d hooks of %d fired before the destructor returned, %d wrong\n", g_hooks.load(), n, g_hook_bad.load());
+    return g_hooks.load() == n && g_hook_bad.load() == 0 ? 0 : 1;
+}
+
+int main() { return scenario(1) | scenario(3) | scenario_drain(); }

@@ -344,3 +344,22 @@ def test_reserve_sizes_buffers_and_changes_no_result(pool, ctx, oc, bbp):
     with pytest.raises(bbp.BbpError) as e:
         pool.reserve(16, 203)
     assert e.value.status == 2
+
+
+def test_free_runs_the_asynchronous_requests_still_queued(bbp, ctx, oc):
+    """bbp_free with asynchronous requests still in the combiner's queue: they are run first -- every callback fires with the
+    oracle's record -- and only then is the device state taken away (include/bbp.h)."""
+    N, B = 3, 10
+    ins, ents, vins = _synth_batch(ctx, B, N, seed=777001)
+    exp, est = oc.prove_many(b"".join(ins), b"".join(ents), B, N, threads=4)
+    rs_ = bbp.record_size(N)
+    c = bbp.Context(0)
+    c.set_batching(20000, 0)   # a 20 ms window: the requests are still queued when close() is called
+    got, keep = {}, []
+    for i in range(B):
+        keep.append(c.prove_async(ins[i][:224], ins[i][224:224 + 32 * N], int.from_bytes(ins[i][-8:], "little"), ents[i],
+                                  (lambda i: lambda status, rec: got.__setitem__(i, (status, rec)))(i)))
+    c.close()
+    assert len(got) == B
+    for i in range(B):
+        assert got[i] == (0, exp[i * rs_:(i + 1) * rs_]), i
