@@ -254,3 +254,25 @@ def test_cli_mirrors_the_reference_flags(built):
     assert p.returncode == 2 and "invalid log level" in p.stderr           # clap possible_values (src/main.rs:33)
     p = subprocess.run([built.SERVER_BIN, "--engine", "/nonexistent.so", "-b", "/tmp/bbp-nope"], capture_output=True, text=True)
     assert p.returncode == 1 and "cannot load engine" in p.stderr
+
+
+def test_load_generator_closed_and_open_loop_against_the_stub(built):
+    """tools/uds_bench.py --stub: the measurement plumbing of configs[4] through the socket on a CPU box -- server (epoll front end,
+    asynchronous engine calls, --reserve, a two-member stub pool), bbp-uds-loadgen in closed-loop and in open-loop (Poisson) mode.
+    Not a measurement: every op must complete, none may fail or be rejected, and the open-loop run must finish its arrivals."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "uds_bench.py")
+    closed = subprocess.run([sys.executable, tool, "--stub", "--connections", "96", "--ops", "1536", "--devices", "0,1"], capture_output=True, text=True, timeout=120)
+    assert closed.returncode == 0, closed.stderr[-800:]
+    d = json.loads(closed.stdout.strip().splitlines()[-1])
+    assert d["mode"] == "closed-loop" and d["ops"] == 1536 and d["failed"] == 0 and d["rejected"] == 0
+    assert d["server"]["errors"] == 0 and d["server"]["device_calls"] < d["server"]["requests"]
+    opened = subprocess.run([sys.executable, tool, "--stub", "--connections", "512", "--rate", "3000", "--duration", "1.5"], capture_output=True, text=True,
+                            timeout=120)
+    assert opened.returncode == 0, opened.stderr[-800:]
+    d = json.loads(opened.stdout.strip().splitlines()[-1])
+    assert d["mode"].startswith("open-loop") and d["failed"] == 0 and d["rejected"] == 0
+    assert d["ops"] == d["arrivals"] and 0.7 * 3000 * 1.5 < d["arrivals"] < 1.3 * 3000 * 1.5
+    assert d["op_latency_ms"]["p50"] > 0 and d["max_client_backlog"] == 0
