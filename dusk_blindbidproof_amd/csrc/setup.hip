@@ -142,6 +142,8 @@ static int32_t init_body(int32_t device, bbp_ctx** out) {
     {  // the prover's opening stage lasts ~36 ms whatever the batch size: a second batch starts no earlier
         const char* e = getenv("BBP_BATCH_STAGGER_US");
         static_cast<Combiner*>(ctx->combiner)->set_stagger(e ? (uint32_t)atoi(e) : 35000u);
+        const char* ss = getenv("BBP_BATCH_STAGGER_SMALL_US");  // behind a batch of at most 256 proofs (cooperative rng chain: a ~13 ms opening stage)
+        static_cast<Combiner*>(ctx->combiner)->set_small_stagger(256, ss ? (uint32_t)atoi(ss) : 15000u);
         const char* sp = getenv("BBP_BATCH_SPLIT_MIN");  // 1024: halves that still run at the engine's large-batch rate
         static_cast<Combiner*>(ctx->combiner)->set_split_min(sp ? (uint32_t)atoi(sp) : 1024u);
         const char* qc = getenv("BBP_BATCH_QUIET_CAP_US");  // a next batch's opening stage (~40 ms) fits under a 1024-proof MSM stage (~48 ms) with 8 ms to spare

@@ -45,6 +45,12 @@ void Combiner::set_hold(int32_t margin_us, uint32_t open_us, double per_proof_us
     per_proof_us_ = per_proof_us;
 }
 
+void Combiner::set_small_stagger(uint32_t small_batch, uint32_t us) {
+    std::lock_guard<std::mutex> lk(mu_);
+    small_batch_ = small_batch;
+    small_stagger_us_ = us;
+}
+
 void Combiner::set_split_min(uint32_t n) {
     std::lock_guard<std::mutex> lk(mu_);
     split_min_ = n;
@@ -169,7 +175,9 @@ void Combiner::thread_main(int kind) {
         targets_[ti].running[kind]++;
         if (stagger_us_ && targets_[ti].prove_inflight > 0 && q_.front()->kind == 0) {  // a PROVE batch is on that device and this would be another:
             // let it grow until that one's opening stage is over (verifications have no such stage and never wait here)
-            const auto start_at = targets_[ti].last_start + std::chrono::microseconds(stagger_us_);
+            // (a small batch's opening stage is the cooperative rng chain, ~12-15 ms instead of ~37: the next batch may follow sooner)
+            const auto start_at = targets_[ti].last_start +
+                                  std::chrono::microseconds(targets_[ti].last_size <= small_batch_ && small_stagger_us_ < stagger_us_ ? small_stagger_us_ : stagger_us_);
             while (!stop_ && targets_[ti].prove_inflight > 0 && q_.size() < max_batch_ && wait_until_steady(cv_window_, lk, start_at) != std::cv_status::timeout) {
             }
             // ... nor before its own MSM stage could start anyway: the batch in flight is expected to end at est_end (below), this
@@ -238,6 +246,7 @@ void Combiner::thread_main(int kind) {
             targets_[ti].est_end = base + std::chrono::microseconds((long long)(per_proof_us_ * (double)batch.size()));
             targets_[ti].prove_inflight++;
             targets_[ti].last_start = now;
+            targets_[ti].last_size = (uint32_t)batch.size();
         }
         bbp_ctx* const where = targets_[ti].ctx;
         lk.unlock();

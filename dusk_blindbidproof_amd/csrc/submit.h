@@ -77,6 +77,8 @@ class Combiner {
     // the length of the opening stage (the next batch's opening cannot begin earlier anyway), and meanwhile the batch grows --
     // without it a few hundred closed-loop callers fragment into many small batches that each pay the full latency floor.
     void set_stagger(uint32_t us);
+    // behind a prove batch of at most `small_batch` proofs the stagger is `us` instead (their opening stage is shorter)
+    void set_small_stagger(uint32_t small_batch, uint32_t us);
     // Behind a busy device a prove batch leaves only when the queue has stopped growing for `quiet_us`, at most `cap_us` after its
     // stagger is over (0 = off).
     void set_quiet(uint32_t quiet_us, uint32_t cap_us);
@@ -94,6 +96,7 @@ class Combiner {
         int running[2] = {0, 0};  // combined calls reserved / running on this target, per kind (0 = prove, 1 = verify)
         int prove_inflight = 0;  // prove batches among them
         std::chrono::steady_clock::time_point last_start{};  // start of the last prove batch (stagger)
+        uint32_t last_size = 0;                              // ... and its size
         std::chrono::steady_clock::time_point est_end{};     // when the prove batches dealt to this target so far are expected to be done
         uint64_t n_calls = 0, n_requests = 0;
     };
@@ -122,6 +125,7 @@ class Combiner {
     int max_leaders_locked() const { return LEADERS_PER_TARGET * (int)(targets_.empty() ? 1 : targets_.size()); }
     uint32_t window_us_ = 0, max_batch_ = 4096, stagger_us_ = 0, split_min_ = 0, quiet_us_ = 300, quiet_cap_us_ = 0, open_us_ = 40000;
     int32_t hold_margin_us_ = -1;
+    uint32_t small_batch_ = 0, small_stagger_us_ = 0xffffffffu;
     double per_proof_us_ = 48.0;
     uint64_t n_calls_ = 0, n_requests_ = 0;
     uint32_t max_seen_ = 0;
