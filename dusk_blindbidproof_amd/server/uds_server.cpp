@@ -118,7 +118,7 @@ static int g_max_conn = 65536;
 static volatile sig_atomic_t g_stop = 0;
 static int g_listen_fd = -1;
 
-constexpr uint64_t MAX_FRAME = 1u << 20;  // the largest legitimate request (verify, N = 202) is ~ 16 KB
+constexpr uint64_t MAX_FRAME = 1u << 16;  // the largest legitimate request (verify, N = 202) is ~ 16 KB; per-connection buffering is bounded by 2 x this
 
 // ---- one connection ---------------------------------------------------------------------------------------------------------------
 struct Conn {
@@ -164,7 +164,6 @@ struct Reactor {
 };
 static std::vector<std::unique_ptr<Reactor>> g_reactors;
 
-static void set_nonblock(int fd) { fcntl(fd, F_SETFL, fcntl(fd, F_GETFL, 0) | O_NONBLOCK); }
 
 // engine thread: hand the finished request to its connection's I/O thread and return at once (include/bbp.h bbp_done_fn)
 static void on_engine_done(void* user, int32_t status) {
