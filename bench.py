@@ -28,7 +28,7 @@ import os
 # number of hardware queues.  Any other stream used before it (torch.distributed's RCCL stream in the multi-rank run) makes
 # two of them share a queue and serialise: measured 84.5 vs 61.6 ms per batch (tools/hwq_probe.py).  Must be set before the HIP
 # runtime initialises, i.e. before the first torch.cuda call.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import argparse
 import json
@@ -132,7 +132,7 @@ def exclusive_pass(wl, bbp, torch, device, dev_index, alu_peak, steps=3):
             w2.drain()
             torch.cuda.synchronize()
             if os.environ.get("BBP_BENCH_NO_CHECK") != "1" and not wl.same_results(w2):
-                raise SystemExit("PARITY FAILURE: the exclusive (one-slice) schedule and the shipped schedule disagree")
+                raise SystemExit("PARITY FAILURE: the exclusive (one-slice) schedule and the shipped schedule disagree" + wl.describe_difference(w2))
             ctx2.set_profiling(True)
             ctx2.last_timings()
             t0 = time.perf_counter()

@@ -142,6 +142,9 @@ class _Base:
         workload has no exclusive form."""
         return None
 
+    def describe_difference(self, other):
+        return ""
+
 
 class StubWorkload(_Base):
     """BBP_BENCH_STUB=1 only: no engine, no GPU -- lets tests/test_bench_launcher.py drive bench.py's N-rank launch path (process
@@ -196,6 +199,7 @@ class MsmWorkload(_Base):
         w = copy.copy(self)
         w.ctx = ctx2
         w.out = [self.torch.zeros_like(o) for o in self.out]
+        self.torch.cuda.synchronize()  # (zero-fill on torch's stream before another context's stream writes the tensors)
         return w
 
     def same_results(self, other):
@@ -286,6 +290,7 @@ class ProveWorkload(_Base):
         w = copy.copy(self)
         w.ctx = ctx2
         w.out_dev = self.torch.zeros_like(self.out_dev)
+        self.torch.cuda.synchronize()  # (zero-fill on torch's stream before another context's stream writes the tensor)
         return w
 
     def same_results(self, other):
@@ -373,6 +378,7 @@ class VerifyWorkload(_Base):
         self.lane_status = [torch.full((batch,), -1, dtype=torch.int32, device=device) for _ in range(self.lanes)]
         self.status = self.lane_status[0]
         self.k = 0
+        torch.cuda.synchronize()  # (the status tensors are filled by torch's stream, written by the lanes' streams: order them once)
         self.units_per_step = batch
         self.alg_bytes_per_step = batch * ((4135 + items) * 160 + 32)   # verify = 4135 + N terms
         self.row_additions_per_step = batch * 4098 * NAF12_DIGITS      # the fixed-base mega-check MSM launch
@@ -394,10 +400,19 @@ class VerifyWorkload(_Base):
         w.status = w.lane_status[0]
         w.k = 0
         w.config = dict(self.config)
+        # the fill above is a kernel on torch's CURRENT stream; the verification writes the same tensor from a lane's stream: without
+        # this the fill may land after the verdicts (seen once two ranks shared a card: 256 statuses of -1)
+        self.torch.cuda.synchronize()
         return w
 
     def same_results(self, other):
         return bool((self.status == other.status).all())
+
+    def describe_difference(self, other):
+        a, b = self.status.cpu().tolist(), other.status.cpu().tolist()
+        diff = [(i, x, y) for i, (x, y) in enumerate(zip(a, b)) if x != y]
+        return ": %d of %d statuses differ, first (index, shipped, exclusive): %r; corrupted indices %r; lanes %d, calls so far %d" % (
+            len(diff), len(a), diff[:8], self.bad[:8], self.lanes, self.k)
 
     def _lane(self):
         i = self.k % self.lanes

@@ -4,7 +4,7 @@ import os
 
 # four engine streams per context = HIP's default number of hardware queues; one more active stream in the process and two of
 # them share a queue.  Only effective if the HIP runtime has not initialised yet; harmless otherwise.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # BBP_LIB_VARIANT=name loads libbbp_hip.name.so: experiment builds of the same sources with other -D knobs (tools/build_variant.py)

@@ -114,11 +114,11 @@ struct bbp_ctx {
     hipEvent_t ev_open[PROVE_BUFS] = {nullptr, nullptr, nullptr}, ev_done[PROVE_BUFS] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_entry[PROVE_BUFS] = {nullptr, nullptr, nullptr};  // caller's stream at entry of a prove call: out_dev is not written before it
     bool ev_done_valid[PROVE_BUFS] = {false, false, false}, ev_open_valid[PROVE_BUFS] = {false, false, false};
-    int verify_overlap = 0;                              // BBP_VERIFY_OVERLAP=1: the variable-base kernels on a side stream (round 3: measured slower with chained accumulates, 6.8 vs 6.3 ms per 1024)
-    // The verifier lanes' MSM accumulate launches are chained by events so that no two of them are co-resident: each then runs beside
-    // the other lanes' thin front-end kernels only, and the lanes settle out of phase (BBP_VERIFY_SERIAL_ACC=0: free-running lanes
-    // lock in phase -- all thin chains together, then all accumulates together, the machine idling in between)
-    int verify_serial_acc = 1;
+    int verify_overlap = 1;                              // BBP_VERIFY_OVERLAP: lane 0's variable-base kernels on a side stream (no measurable difference with four lanes)
+    // BBP_VERIFY_SERIAL_ACC=1: the verifier lanes' MSM accumulate launches are chained by events so that no two of them are
+    // co-resident (each then runs beside the other lanes' thin front-end kernels only).  Helps two lanes that share hardware queues
+    // with other streams (6.5 -> 6.3 ms per 1024); with four lanes on queues of their own free-running is faster (5.2 vs 6.05 ms): off.
+    int verify_serial_acc = 0;
     static constexpr int VACC_RING = 4;
     hipEvent_t ev_vacc[VACC_RING] = {};
     uint32_t vacc_seq = 0;
@@ -135,7 +135,10 @@ struct bbp_ctx {
     // two families with disjoint scratch: 0 = prover, MSM hook, witness, setup read-backs; 1 = verifier (its own batch buffer,
     // misc scratch and MSM scratch slot VERIFY_SLOT) -- a verification issued on another stream than a prove call is NOT ordered
     // behind it and overlaps its heavy stage on the device
-    static constexpr int VLANES = 2;             // (the code takes any number; three lanes measured 8-10 % SLOWER than two, see below)
+#ifndef BBP_VLANES
+#define BBP_VLANES 4
+#endif
+    static constexpr int VLANES = BBP_VLANES;    // four lanes -- with enough hardware queues (GPU_MAX_HW_QUEUES >= 16), see below
     static constexpr int FAMILIES = 1 + VLANES;  // prover | one per verifier lane
     hipStream_t last_stream[FAMILIES] = {};
     hipEvent_t ev_last[FAMILIES] = {};
@@ -144,9 +147,10 @@ struct bbp_ctx {
     // buffers, a stream): two calls on the two lanes share nothing, so the front end of one (parse, transcripts, powers, flatten,
     // scalars: latency-bound) runs under the MSM of the other.  The host-pointer API alternates lanes with its staging slots;
     // device-API callers pick a lane by passing that lane's stream (bbp_context_verify_stream), any other stream is lane 0.
-    // Two lanes.  A 1024-proof call is a chain of ~10 ms of kernels of which only the 4 ms MSM accumulate fills the machine; a
-    // third chain in flight was tried in round 3 (VLANES = 3) and lost: 7.2 instead of 6.3-6.5 ms per call -- the front-end kernels of
-    // two other calls slow each other and the accumulate more than the extra overlap gives back.
+    // FOUR lanes (round 3; two before).  A 1024-proof call is a chain of ~10 ms of kernels of which only the 4 ms MSM accumulate fills
+    // the machine, so several chains must be in flight.  A third lane first measured 8-10 % SLOWER than two -- because its stream
+    // shared a HARDWARE QUEUE with another lane's (GPU_MAX_HW_QUEUES was 8, the context creates 9+ streams): with 16 queues, 1024
+    // verifications per call take 6.3 ms on two lanes, 5.45 on three, 5.17 on four, 5.45 / 5.25 on five / six.
     struct VLane {
         hipStream_t stream = nullptr;
         bbp::DevBuf misc, agg, agg_io;

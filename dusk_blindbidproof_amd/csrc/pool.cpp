@@ -172,6 +172,7 @@ extern "C" int32_t bbp_pool_init(const int32_t* devices, uint32_t n_devices, bbp
         if (const char* e = getenv("BBP_BATCH_WINDOW_US")) c->configure((uint32_t)atoi(e), 0);
         const char* e = getenv("BBP_BATCH_STAGGER_US");
         c->set_stagger(e ? (uint32_t)atoi(e) : 35000u);
+        c->set_leaders(1, bbp_ctx::VLANES);
         const char* ss = getenv("BBP_BATCH_STAGGER_SMALL_US");
         c->set_small_stagger(256, ss ? (uint32_t)atoi(ss) : 15000u);
         const char* sp = getenv("BBP_BATCH_SPLIT_MIN");

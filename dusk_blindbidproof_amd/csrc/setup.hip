@@ -142,6 +142,7 @@ static int32_t init_body(int32_t device, bbp_ctx** out) {
     {  // the prover's opening stage lasts ~36 ms whatever the batch size: a second batch starts no earlier
         const char* e = getenv("BBP_BATCH_STAGGER_US");
         static_cast<Combiner*>(ctx->combiner)->set_stagger(e ? (uint32_t)atoi(e) : 35000u);
+        static_cast<Combiner*>(ctx->combiner)->set_leaders(1, bbp_ctx::VLANES);  // one verification batch in flight per verifier lane
         const char* ss = getenv("BBP_BATCH_STAGGER_SMALL_US");  // behind a batch of at most 256 proofs (cooperative rng chain: a ~13 ms opening stage)
         static_cast<Combiner*>(ctx->combiner)->set_small_stagger(256, ss ? (uint32_t)atoi(ss) : 15000u);
         const char* sp = getenv("BBP_BATCH_SPLIT_MIN");  // 1024: halves that still run at the engine's large-batch rate
@@ -379,13 +380,15 @@ extern "C" int32_t bbp_describe(bbp_ctx* ctx, char* buf, uint32_t cap) {
                                           ctx->device, prop.name, prop.gcnArchName, prop.multiProcessorCount, prop.clockRate / 1e3, free_b / 1073741824.0,
                                           total_b / 1073741824.0, ctx->slices, ctx->tail_round, ctx->rng_coop_below, (int)bbp_ctx::VLANES,
                                           ctx->verify_serial_acc ? "chained" : "free-running", ctx->verify_group, ctx->verify_group ? "" : " (off)");
-        // The engine keeps four streams busy during a prove call (caller's, opening stage, two more slices) and up to three more for
-        // verification: HIP's default of four hardware queues makes two of them share one and serialise (measured 84.5 vs 61.6 ms per
-        // batch).  The variable is read when the HIP runtime initialises, i.e. possibly long before bbp_init.
-        if ((!hwq || atoi(hwq) < 8) && off + 1 < cap)
+        // The engine keeps four streams busy during a prove call (caller's, opening stage, two more slices) and four more for
+        // verification (one per lane), out of eleven it creates: HIP's default of four hardware queues makes them share and serialise
+        // (measured 84.5 vs 61.6 ms per prove batch; a third verifier lane on 8 queues made verification 10 %% SLOWER, on 16 it is 13 %%
+        // faster: INTEGRATION.md section 5).  The variable is read when the HIP runtime initialises, i.e. possibly long before bbp_init.
+        if ((!hwq || atoi(hwq) < 16) && off + 1 < cap)
             off += (uint32_t)snprintf(buf + off, cap - off,
-                                      "WARNING: GPU_MAX_HW_QUEUES is %s: export GPU_MAX_HW_QUEUES=8 before the process first touches HIP, or streams of this "
-                                      "context may share a hardware queue and serialise (up to ~30 %% slower batches)\n",
+                                      "WARNING: GPU_MAX_HW_QUEUES is %s: export GPU_MAX_HW_QUEUES=16 before the process first touches HIP, or streams of this "
+                                      "context share hardware queues and serialise (prover up to ~30 %% slower with the default of 4; verifier 5.2 -> 7 ms per "
+                                      "1024 with 8)\n",
                                       hwq ? hwq : "not set");
         if (free_b < ((size_t)6 << 30) && off + 1 < cap)
             off += (uint32_t)snprintf(buf + off, cap - off, "WARNING: less than 6 GiB of device memory free: a 1024-proof batch needs ~14 GiB of scratch\n");

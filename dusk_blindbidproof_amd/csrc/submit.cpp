@@ -51,6 +51,11 @@ void Combiner::set_small_stagger(uint32_t small_batch, uint32_t us) {
     small_stagger_us_ = us;
 }
 
+void Combiner::set_leaders(int kind, int n) {
+    std::lock_guard<std::mutex> lk(mu_);
+    if ((kind == 0 || kind == 1) && n >= 1 && n <= 16) leaders_[kind] = n;
+}
+
 void Combiner::set_split_min(uint32_t n) {
     std::lock_guard<std::mutex> lk(mu_);
     split_min_ = n;
@@ -120,7 +125,7 @@ bool Combiner::enqueue_locked(bbp_ctx* ctx, Request* r) {
     }
     const int kind = r->kind ? 1 : 0;
     Lane& L = lane_[kind];
-    while (L.n_threads < max_leaders_locked()) {  // prove and verify requests have their own queue and their own batch threads:
+    while (L.n_threads < max_leaders_locked(kind)) {  // prove and verify requests have their own queue and their own batch threads:
         try {                                     // a verification never waits for a thread that sits in a 100 ms prove call
             threads_.emplace_back([this, kind] { thread_main(kind); });
             L.n_threads++;

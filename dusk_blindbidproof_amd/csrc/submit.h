@@ -77,6 +77,8 @@ class Combiner {
     // the length of the opening stage (the next batch's opening cannot begin earlier anyway), and meanwhile the batch grows --
     // without it a few hundred closed-loop callers fragment into many small batches that each pay the full latency floor.
     void set_stagger(uint32_t us);
+    // batch threads per target for requests of `kind` (0 prove, 1 verify): as many verification batches in flight as the engine has verifier lanes
+    void set_leaders(int kind, int n);
     // behind a prove batch of at most `small_batch` proofs the stagger is `us` instead (their opening stage is shorter)
     void set_small_stagger(uint32_t small_batch, uint32_t us);
     // Behind a busy device a prove batch leaves only when the queue has stopped growing for `quiet_us`, at most `cap_us` after its
@@ -122,7 +124,8 @@ class Combiner {
     void thread_main(int kind);
     static constexpr int LEADERS_PER_TARGET = 2;  // three (as many as there are staging slots) fragments closed-loop load into more, smaller batches:
                                                   // measured through the UDS server 14.7 k -> 11.5 k proofs/s prove-only, 8.2 k -> 7.1 k ops/s at 2048 connections
-    int max_leaders_locked() const { return LEADERS_PER_TARGET * (int)(targets_.empty() ? 1 : targets_.size()); }
+    int leaders_[2] = {LEADERS_PER_TARGET, LEADERS_PER_TARGET};  // batch threads per target for prove / verify requests (set_leaders)
+    int max_leaders_locked(int kind) const { return leaders_[kind] * (int)(targets_.empty() ? 1 : targets_.size()); }
     uint32_t window_us_ = 0, max_batch_ = 4096, stagger_us_ = 0, split_min_ = 0, quiet_us_ = 300, quiet_cap_us_ = 0, open_us_ = 40000;
     int32_t hold_margin_us_ = -1;
     uint32_t small_batch_ = 0, small_stagger_us_ = 0xffffffffu;

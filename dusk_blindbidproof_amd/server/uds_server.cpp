@@ -575,6 +575,9 @@ int main(int argc, char** argv) {
         dir = dir.substr(0, dir.find_last_of('/'));
         engine_path = dir.substr(0, dir.find_last_of('/')) + "/libbbp_hip.so";
     }
+    // the engine creates eleven streams per context and keeps up to eight busy: HIP's default of four hardware queues makes them share
+    // and serialise.  Read when the HIP runtime initialises, i.e. at the engine's first call: set it before the library is loaded.
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
     std::string why;
     if (!g_eng.load(engine_path.c_str(), &why)) {
         logf(0, "cannot load engine %s: %s", engine_path.c_str(), why.c_str());

@@ -105,7 +105,7 @@ void* bbp_context_stream(bbp_ctx* ctx);
  * bbp_prepare_bids_dev) while the first one carries prove / verify calls: same reason as above -- created at bbp_init beside
  * the engine's streams, it does not share a hardware queue with them. */
 void* bbp_context_copy_stream(bbp_ctx* ctx);
-/* The verifier has two independent lanes (own scratch each): calls issued on the streams of different lanes (lane < 2; NULL beyond)
+/* The verifier has four independent lanes (own scratch each): calls issued on the streams of different lanes (lane < 4; NULL beyond)
  * overlap on the device -- the latency-bound front end of one runs under the MSM of another -- instead of being ordered one behind
  * the other like calls on any other pair of streams.  The host-pointer verify calls rotate over the lanes by themselves. */
 void* bbp_context_verify_stream(bbp_ctx* ctx, uint32_t lane);
@@ -232,7 +232,7 @@ int32_t bbp_debug_compile_circuit(uint32_t N, uint32_t* n_mul, uint32_t* n_cons)
 
 /* Diagnostics: a short text report of what the context (every member of a pool) runs on and how it is configured -- device, free
  * memory, scheduling knobs -- into buf (NUL-terminated, truncated to cap).  Conditions known to cost throughput silently are
- * reported as lines starting with "WARNING:" (today: GPU_MAX_HW_QUEUES below 8 in the environment, little free device memory). */
+ * reported as lines starting with "WARNING:" (today: GPU_MAX_HW_QUEUES below 16 in the environment, little free device memory). */
 int32_t bbp_describe(bbp_ctx* ctx, char* buf, uint32_t cap);
 
 /* Test hook: poisons the sorted scratch of the context's NEXT MSM launch with an out-of-range entry (what a stray write would leave).

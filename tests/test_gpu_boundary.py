@@ -244,9 +244,9 @@ def test_corrupted_scratch_fails_the_call_instead_of_returning_a_wrong_proof(bbp
 
 def test_describe_reports_device_and_warns_about_hardware_queues(ctx, bbp):
     """bbp_describe: the device line is there, and the hardware-queue condition that silently costs up to 30 % (INTEGRATION.md
-    section 5) is either satisfied in this process (the binding exports GPU_MAX_HW_QUEUES=8 before HIP initialises) or WARNed about."""
+    section 5) is either satisfied in this process (the binding exports GPU_MAX_HW_QUEUES=16 before HIP initialises) or WARNed about."""
     import os
     text = ctx.describe()
-    assert "gfx950" in text and "CUs" in text and "verifier: 2 lanes" in text
+    assert "gfx950" in text and "CUs" in text and "verifier: 4 lanes" in text
     hwq = os.environ.get("GPU_MAX_HW_QUEUES")
-    assert ("WARNING: GPU_MAX_HW_QUEUES" in text) == (hwq is None or int(hwq) < 8)
+    assert ("WARNING: GPU_MAX_HW_QUEUES" in text) == (hwq is None or int(hwq) < 16)

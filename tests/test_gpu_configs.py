@@ -188,10 +188,11 @@ def test_aggregated_verification_is_stream_ordered(ctx, bbp):
         assert {i for i, v in enumerate(got) if v != 0} == bad, k
 
 
-def test_two_verifier_lanes_share_nothing(ctx, bbp):
-    """bbp_context_verify_stream(0 / 1): calls on the two lanes' streams run concurrently on the device (own batch buffer, scratch,
-    MSM scratch slot and aggregation buffers each).  Eight calls alternate lanes with no synchronisation in between, per-proof and
-    aggregated mixed, every call over a different corruption pattern and batch size: each must report exactly its own pattern."""
+def test_verifier_lanes_share_nothing(ctx, bbp):
+    """bbp_context_verify_stream(lane): calls on different lanes' streams run concurrently on the device (own batch buffer, scratch,
+    MSM scratch slot and aggregation buffers each; four lanes since round 3).  Twelve calls rotate over the lanes with no
+    synchronisation in between, per-proof and aggregated mixed, every call over a different corruption pattern and batch size:
+    each must report exactly its own pattern."""
     import torch
     dev = torch.device("cuda", 0)
     N, distinct = 8, 40
@@ -199,10 +200,14 @@ def test_two_verifier_lanes_share_nothing(ctx, bbp):
     out, st = ctx.prove_batch(distinct, N, b"".join(ins), b"".join(ents))
     assert st == [0] * distinct
     rs_ = bbp.record_size(N)
-    lanes = [torch.cuda.ExternalStream(ctx.verify_stream(i), device=dev) for i in range(2)]
-    assert lanes[0].cuda_stream != lanes[1].cuda_stream
+    n_lanes = 0
+    while ctx.verify_stream(n_lanes):
+        n_lanes += 1
+    assert n_lanes == 4 and ctx.verify_stream(n_lanes) is None
+    lanes = [torch.cuda.ExternalStream(ctx.verify_stream(i), device=dev) for i in range(n_lanes)]
+    assert len({x.cuda_stream for x in lanes}) == n_lanes
     calls = []
-    for k in range(8):
+    for k in range(12):
         B = (300, 517, 64, 1000)[k % 4]
         bad = {(7 * k + 11 * j) % B for j in range(k)}          # call 0 is all honest
         rows = [bytearray(out[(i % distinct) * rs_:(i % distinct + 1) * rs_] + b"".join(vins[i % distinct])) for i in range(B)]
@@ -212,7 +217,7 @@ def test_two_verifier_lanes_share_nothing(ctx, bbp):
         calls.append((B, bad, d_in, torch.zeros(32 * B, dtype=torch.uint8, device=dev), torch.full((B,), -1, dtype=torch.int32, device=dev)))
     torch.cuda.synchronize()
     for k, (B, bad, d_in, d_ent, d_st) in enumerate(calls):
-        s = lanes[k & 1].cuda_stream
+        s = lanes[k % n_lanes].cuda_stream
         if k % 3 == 2:
             ctx.verify_batch_aggregated_dev(B, N, d_in.data_ptr(), d_ent.data_ptr(), d_st.data_ptr(), 16, s, want_count=False)
         else:

@@ -34,7 +34,12 @@ def _bench_two_ranks(args):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-build", "--no-also", "--no-cpu-baseline"] + args,
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
-    assert p.returncode == 0, (p.stdout.decode()[-1500:], p.stderr.decode()[-3000:])
+    if p.returncode != 0:  # keep the ranks' whole stderr where gpurun brings it back
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "two_ranks_failure.err"), "wb") as f:
+            f.write(p.stderr)
+    err = [ln for ln in p.stderr.decode().splitlines() if "Gloo" not in ln and "amdgpu.ids" not in ln and "hostname of the client" not in ln]
+    assert p.returncode == 0, (p.stdout.decode()[-1500:], "\n".join(err)[-3000:])
     lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout.decode()[-1500:]
     return json.loads(lines[0])

@@ -12,7 +12,7 @@ entropy per chunk so every proof is different.
 import argparse, hashlib, json, os, sys, time
 # the engine itself keeps four streams busy (caller's + opening + two more slices) = HIP's default number of hardware queues;
 # this tool adds a copy stream, and a fifth stream would share a queue with one of them and serialise behind it
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
