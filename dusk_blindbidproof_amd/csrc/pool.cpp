@@ -178,7 +178,8 @@ extern "C" int32_t bbp_pool_init(const int32_t* devices, uint32_t n_devices, bbp
         const char* sp = getenv("BBP_BATCH_SPLIT_MIN");
         c->set_split_min(sp ? (uint32_t)atoi(sp) : 1024u);
         const char* qc = getenv("BBP_BATCH_QUIET_CAP_US");
-        c->set_quiet(300, qc ? (uint32_t)atoi(qc) : 8000u);
+        const char* qu = getenv("BBP_BATCH_QUIET_US");
+        c->set_quiet(qu ? (uint32_t)atoi(qu) : 300u, qc ? (uint32_t)atoi(qc) : 8000u);
         const char* hm = getenv("BBP_BATCH_HOLD_MARGIN_US");
         c->set_hold(hm ? atoi(hm) : 4000, 40000u, 48.0);
         return BBP_OK;

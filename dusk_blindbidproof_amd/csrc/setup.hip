@@ -148,7 +148,8 @@ static int32_t init_body(int32_t device, bbp_ctx** out) {
         const char* sp = getenv("BBP_BATCH_SPLIT_MIN");  // 1024: halves that still run at the engine's large-batch rate
         static_cast<Combiner*>(ctx->combiner)->set_split_min(sp ? (uint32_t)atoi(sp) : 1024u);
         const char* qc = getenv("BBP_BATCH_QUIET_CAP_US");  // a next batch's opening stage (~40 ms) fits under a 1024-proof MSM stage (~48 ms) with 8 ms to spare
-        static_cast<Combiner*>(ctx->combiner)->set_quiet(300, qc ? (uint32_t)atoi(qc) : 8000u);
+        const char* qu = getenv("BBP_BATCH_QUIET_US");
+        static_cast<Combiner*>(ctx->combiner)->set_quiet(qu ? (uint32_t)atoi(qu) : 300u, qc ? (uint32_t)atoi(qc) : 8000u);
         const char* hm = getenv("BBP_BATCH_HOLD_MARGIN_US");  // -1 = off
         static_cast<Combiner*>(ctx->combiner)->set_hold(hm ? atoi(hm) : 4000, 40000u, 48.0);  // ~40 ms opening stage, ~48 us per proof
     }
@@ -382,13 +383,15 @@ extern "C" int32_t bbp_describe(bbp_ctx* ctx, char* buf, uint32_t cap) {
                                           ctx->verify_serial_acc ? "chained" : "free-running", ctx->verify_group, ctx->verify_group ? "" : " (off)");
         // The engine keeps four streams busy during a prove call (caller's, opening stage, two more slices) and four more for
         // verification (one per lane), out of eleven it creates: HIP's default of four hardware queues makes them share and serialise
-        // (measured 84.5 vs 61.6 ms per prove batch; a third verifier lane on 8 queues made verification 10 %% SLOWER, on 16 it is 13 %%
-        // faster: INTEGRATION.md section 5).  The variable is read when the HIP runtime initialises, i.e. possibly long before bbp_init.
-        if ((!hwq || atoi(hwq) < 16) && off + 1 < cap)
+        // (measured 84.5 vs 61.6 ms per prove batch).  How many are best depends on the mix: 8 for prove-dominated host-pointer use
+        // (the UDS server: 20.4 k proofs/s against 17.1 k with 16), 16 for verification on all four lanes through the device API
+        // (1024 per call: 5.2 ms against 7.2 with 8): INTEGRATION.md section 5.  The variable is read when the HIP runtime
+        // initialises, i.e. possibly long before bbp_init.
+        if ((!hwq || atoi(hwq) < 8) && off + 1 < cap)
             off += (uint32_t)snprintf(buf + off, cap - off,
-                                      "WARNING: GPU_MAX_HW_QUEUES is %s: export GPU_MAX_HW_QUEUES=16 before the process first touches HIP, or streams of this "
-                                      "context share hardware queues and serialise (prover up to ~30 %% slower with the default of 4; verifier 5.2 -> 7 ms per "
-                                      "1024 with 8)\n",
+                                      "WARNING: GPU_MAX_HW_QUEUES is %s: export GPU_MAX_HW_QUEUES=8 (prove-dominated use) or 16 (verification on four lanes) "
+                                      "before the process first touches HIP, or streams of this context share hardware queues and serialise (prover up to "
+                                      "~30 %% slower with the default of 4)\n",
                                       hwq ? hwq : "not set");
         if (free_b < ((size_t)6 << 30) && off + 1 < cap)
             off += (uint32_t)snprintf(buf + off, cap - off, "WARNING: less than 6 GiB of device memory free: a 1024-proof batch needs ~14 GiB of scratch\n");

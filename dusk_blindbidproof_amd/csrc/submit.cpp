@@ -194,6 +194,18 @@ void Combiner::thread_main(int kind) {
                 while (!stop_ && targets_[ti].prove_inflight > 0 && q_.size() < max_batch_ && wait_until_steady(cv_window_, lk, hold_until) != std::cv_status::timeout) {
                 }
             }
+            // ... nor right after ANOTHER batch of this target has come back with far more callers than are queued yet: its callers
+            // (closed-loop clients) are on their way in -- 1834 replies take milliseconds to write and to be answered -- and a thread
+            // whose hold happens to expire in that moment would leave with the first 175 of them, after which the two batches in flight
+            // stay lopsided (175 / 2897 instead of 1536 / 1536: 16 k instead of 20.8 k proofs/s through the socket).  Bounded: 10 ms
+            // after that completion, or until half as many requests as it carried are queued.
+            if (hold_margin_us_ >= 0) {
+                const auto until = targets_[ti].last_done + std::chrono::microseconds(10000);
+                while (!stop_ && targets_[ti].prove_inflight > 0 && q_.size() < max_batch_ && 2 * q_.size() < targets_[ti].last_done_size &&
+                       std::chrono::steady_clock::now() < until) {
+                    wait_until_steady(cv_window_, lk, std::min(until, std::chrono::steady_clock::now() + std::chrono::microseconds(500)));
+                }
+            }
             // ... and while the queue is still GROWING behind a busy device, keep holding back (quiet-period detection, bounded): the
             // callers of a batch that just finished come back as a burst spread over milliseconds -- 1536 replies written and
             // answered one after the other -- and a thread that left with the first few hundred of them would put a small,
@@ -257,7 +269,11 @@ void Combiner::thread_main(int kind) {
         lk.unlock();
         run_batch(where, batch);
         lk.lock();
-        if (proving) targets_[ti].prove_inflight--;
+        if (proving) {
+            targets_[ti].prove_inflight--;
+            targets_[ti].last_done = std::chrono::steady_clock::now();
+            targets_[ti].last_done_size = batch.size();
+        }
         targets_[ti].running[kind]--;
         cv_window_.notify_all();  // a thread holding back behind this batch may go now
         n_calls_++;

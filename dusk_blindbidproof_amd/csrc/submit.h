@@ -99,6 +99,8 @@ class Combiner {
         int prove_inflight = 0;  // prove batches among them
         std::chrono::steady_clock::time_point last_start{};  // start of the last prove batch (stagger)
         uint32_t last_size = 0;                              // ... and its size
+        std::chrono::steady_clock::time_point last_done{};   // when the last prove batch of this target came back ...
+        size_t last_done_size = 0;                           // ... and how many callers it carried
         std::chrono::steady_clock::time_point est_end{};     // when the prove batches dealt to this target so far are expected to be done
         uint64_t n_calls = 0, n_requests = 0;
     };

@@ -575,9 +575,12 @@ int main(int argc, char** argv) {
         dir = dir.substr(0, dir.find_last_of('/'));
         engine_path = dir.substr(0, dir.find_last_of('/')) + "/libbbp_hip.so";
     }
-    // the engine creates eleven streams per context and keeps up to eight busy: HIP's default of four hardware queues makes them share
-    // and serialise.  Read when the HIP runtime initialises, i.e. at the engine's first call: set it before the library is loaded.
-    setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    // The engine creates eleven streams per context and keeps up to eight busy: HIP's default of four hardware queues makes them share
+    // and serialise.  Eight is the measured optimum for this server's mix (prove-dominated, host-pointer calls: 20.4 k proofs/s at 3072
+    // connections against 17.1 k with 16 queues; prove + verify at 2048 connections 12.4-12.9 k ops/s against 12.4-12.5 k) -- the
+    // verifier's four lanes alone would like 16.  Read when the HIP runtime initialises, i.e. at the engine's
+    // first call: set before the library is loaded, and only if the operator has not chosen.
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     std::string why;
     if (!g_eng.load(engine_path.c_str(), &why)) {
         logf(0, "cannot load engine %s: %s", engine_path.c_str(), why.c_str());

@@ -232,7 +232,7 @@ int32_t bbp_debug_compile_circuit(uint32_t N, uint32_t* n_mul, uint32_t* n_cons)
 
 /* Diagnostics: a short text report of what the context (every member of a pool) runs on and how it is configured -- device, free
  * memory, scheduling knobs -- into buf (NUL-terminated, truncated to cap).  Conditions known to cost throughput silently are
- * reported as lines starting with "WARNING:" (today: GPU_MAX_HW_QUEUES below 16 in the environment, little free device memory). */
+ * reported as lines starting with "WARNING:" (today: GPU_MAX_HW_QUEUES below 8 in the environment, little free device memory). */
 int32_t bbp_describe(bbp_ctx* ctx, char* buf, uint32_t cap);
 
 /* Test hook: poisons the sorted scratch of the context's NEXT MSM launch with an out-of-range entry (what a stray write would leave).

@@ -249,4 +249,4 @@ def test_describe_reports_device_and_warns_about_hardware_queues(ctx, bbp):
     text = ctx.describe()
     assert "gfx950" in text and "CUs" in text and "verifier: 4 lanes" in text
     hwq = os.environ.get("GPU_MAX_HW_QUEUES")
-    assert ("WARNING: GPU_MAX_HW_QUEUES" in text) == (hwq is None or int(hwq) < 16)
+    assert ("WARNING: GPU_MAX_HW_QUEUES" in text) == (hwq is None or int(hwq) < 8)
