@@ -513,7 +513,7 @@ static void on_signal(int) {
 static void usage(const char* argv0) {
     fprintf(stderr,
             "usage: %s [-b|--bind-path PATH] [-l|--log-level error|warn|info|debug|trace] [--engine LIB.so] [--device N | --devices 0,1,..]\n"
-            "          [--window-us US] [--max-batch B] [--max-connections C] [--io-threads T] [--reserve N[,N..]]\n",
+            "          [--window-us US] [--max-batch B] [--max-connections C] [--io-threads T] [--reserve N[,N..]] [--verify-aggregate G]\n",
             argv0);
 }
 
@@ -549,6 +549,8 @@ int main(int argc, char** argv) {
         else if (a == "--max-batch") max_batch = (uint32_t)atoi(val());
         else if (a == "--max-connections") g_max_conn = atoi(val());
         else if (a == "--io-threads") io_threads = atoi(val());
+        else if (a == "--verify-aggregate") setenv("BBP_VERIFY_AGGREGATE", val(), 1);  // opcode-2 batches of >= 2 G proofs are checked in groups of G with
+                                                                                         // per-proof fallback: same verdicts, 2-3x the rate (include/bbp.h)
         else if (a == "--reserve") {
             for (const char* p = val(); *p;) {
                 reserve_items.push_back(atoi(p));

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--io-threads", type=int, default=2)
     ap.add_argument("--gen-threads", type=int, default=2)
     ap.add_argument("--preconnect", type=int, default=0, help="open loop: connections opened before the clock starts")
+    ap.add_argument("--verify-aggregate", type=int, default=0, help="server --verify-aggregate G (0 = one MSM per proof like the reference)")
     ap.add_argument("--hwq", type=int, default=int(os.environ.get("BBP_SERVER_HWQ", "8")), help="GPU_MAX_HW_QUEUES of the server process")
     ap.add_argument("--devices", default="0", help="server --devices list (a,b,..: device pool)")
     ap.add_argument("--stub", action="store_true", help="CPU box: the tests' stub engine (plumbing check, not a measurement)")
@@ -61,7 +62,7 @@ def main():
     log = open(os.path.join(d, "server.log"), "w+")
     srv = subprocess.Popen([ge.SERVER_BIN, "-b", sock, "-l", "info", "--engine", engine, "--window-us", str(a.window_us), "--max-batch",
                             str(a.max_batch), "--max-connections", str(max(4096, 2 * a.connections)), "--io-threads", str(a.io_threads),
-                            "--devices", a.devices, "--reserve", str(N)], stderr=log, env=dict(os.environ, GPU_MAX_HW_QUEUES=str(a.hwq)))
+                            "--devices", a.devices, "--reserve", str(N)] + (["--verify-aggregate", str(a.verify_aggregate)] if a.verify_aggregate else []), stderr=log, env=dict(os.environ, GPU_MAX_HW_QUEUES=str(a.hwq)))
     for _ in range(6000):
         if os.path.exists(sock) or srv.poll() is not None:
             break
@@ -90,7 +91,7 @@ def main():
     for run in runs:
         out = json.loads(run.stdout.strip().splitlines()[-1]) if run.stdout.strip() else {"error": run.stderr[-300:], "warmup": warm.stderr[-300:]}
         out.update(workload="configs[4] through the UDS server: %s per connection" % ("prove only" if a.no_verify else "prove then verify"), bid_list_len=N,
-                   window_us=a.window_us, max_batch=a.max_batch, io_threads=a.io_threads, devices=a.devices, server_hw_queues=a.hwq,
+                   window_us=a.window_us, max_batch=a.max_batch, io_threads=a.io_threads, devices=a.devices, server_hw_queues=a.hwq, verify_aggregate=a.verify_aggregate,
                    engine="stub (not a measurement)" if a.stub else "libbbp_hip.so")
         if m and len(runs) == 1:
             out["server"] = dict(requests=int(m.group(1)), errors=int(m.group(2)), device_calls=int(m.group(3)), largest_batch=int(m.group(4)))
