@@ -107,21 +107,28 @@ def roofline(wl, timings, steps, alu_peak=None, wall_s=None):
     return out
 
 
-def exclusive_pass(wl, bbp, torch, device, dev_index, alu_peak, steps=3):
-    """The reproducible roofline figure.  The shipped schedule cuts a batch into slices whose launches overlap in time, so the
-    per-launch durations behind `roofline.frac` are stretched by co-residency.  Here the same inputs go through a SECOND context
-    created with BBP_SLICES=1 (verifier: one lane): no two launches of the dominant kernel overlap, a launch covers the whole batch,
-    and (summed launch time of the dominant kernel per step) is what rocprofv3's exclusive kernel-stats pass shows as well
-    (profiles/README.md).  Results must equal the shipped schedule's byte for byte."""
+def exclusive_context(bbp, dev_index):
+    """A second context created with BBP_SLICES=1 (the environment is read at bbp_init)."""
     old = os.environ.get("BBP_SLICES")
     os.environ["BBP_SLICES"] = "1"
     try:
-        ctx2 = bbp.Context(dev_index)
+        return bbp.Context(dev_index)
     finally:
         if old is None:
             os.environ.pop("BBP_SLICES", None)
         else:
             os.environ["BBP_SLICES"] = old
+
+
+def exclusive_pass(wl, bbp, torch, device, dev_index, alu_peak, steps=3, ctx2=None):
+    """The reproducible roofline figure.  The shipped schedule cuts a batch into slices whose launches overlap in time, so the
+    per-launch durations behind `roofline.frac` are stretched by co-residency.  Here the same inputs go through a SECOND context
+    created with BBP_SLICES=1 (verifier: one lane): no two launches of the dominant kernel overlap, a launch covers the whole batch,
+    and (summed launch time of the dominant kernel per step) is what rocprofv3's exclusive kernel-stats pass shows as well
+    (profiles/README.md).  Results must equal the shipped schedule's byte for byte."""
+    own = ctx2 is None
+    if own:
+        ctx2 = exclusive_context(bbp, dev_index)
     try:
         w2 = wl.clone_for(ctx2)
         if w2 is None:
@@ -158,7 +165,8 @@ def exclusive_pass(wl, bbp, torch, device, dev_index, alu_peak, steps=3):
         import gc
         torch.cuda.synchronize()
         gc.collect()
-        ctx2.close()
+        if own:
+            ctx2.close()
 
 
 def launch_ranks(args, argv):
@@ -340,9 +348,10 @@ def main():
                            "backend": backend if world > 1 else "none (single rank: local copy)", "checked": "sample of every rank's block vs the C oracle"}
         del gathered
 
-    exclusive = None
+    exclusive, ctx_excl = None, None
     if rank == 0 and not STUB and not args.no_exclusive:
-        exclusive = exclusive_pass(wl, bbp, torch, device, dev_index, alu_peak)
+        ctx_excl = exclusive_context(bbp, dev_index)  # kept for the secondary workloads' exclusive passes below
+        exclusive = exclusive_pass(wl, bbp, torch, device, dev_index, alu_peak, ctx2=ctx_excl)
 
     also = {}
     if args.workload == "prove" and not args.no_also and not STUB:
@@ -362,6 +371,10 @@ def main():
             d2 = float(t2max.item())
             also[name] = {"metric": w2.metric, "value": w2.units_per_step * ks * world / d2, "unit": w2.unit, "steps": ks,
                           "ms_per_step": d2 / ks * 1e3, "config": w2.config, "roofline": roofline(w2, t2, ks, alu_peak, d2)}
+            if ctx_excl is not None:  # the un-stretched figure for this workload too (one lane / one slice on the second context)
+                ex = exclusive_pass(w2, bbp, torch, device, dev_index, alu_peak, ctx2=ctx_excl)
+                if ex:
+                    also[name]["roofline"]["exclusive"] = ex
             if rank == 0 and world == 1 and not args.no_cpu_baseline and name == "verify":
                 also[name]["cpu_baseline"] = dict(w2.cpu_baseline(), cpu_model=cpu_model())
             del w2
@@ -385,6 +398,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not STUB:
             out["cpu_baseline"] = dict(wl.cpu_baseline(), cpu_model=cpu_model())
         print(json.dumps(out), flush=True)
+    if ctx_excl is not None:
+        torch.cuda.synchronize()
+        ctx_excl.close()
     if ctx is not None:
         # torch objects that wrap the context's streams (ExternalStream, events recorded on them) must go before bbp_free destroys
         # the streams: an event destructor touching a destroyed stream at interpreter exit is a segfault
