@@ -529,7 +529,16 @@ class StreamWorkload(_Base):
                            d_st=torch.full((C,), -1, dtype=torch.int32, device=device),
                            h_rec=torch.empty(C * self.rec, dtype=torch.uint8).pin_memory(), h_st=torch.empty(C, dtype=torch.int32).pin_memory(),
                            ev_in=torch.cuda.Event(), ev0=torch.cuda.Event(enable_timing=True), ev1=torch.cuda.Event(enable_timing=True),
+                           ev_v=torch.cuda.Event(), ev_rec=torch.cuda.Event(),
                            busy=False, chunk=-1) for _ in range(depth)]
+        # verification of chunk k on one of the verifier's lanes (rotating), so that it runs beside the prove of chunk k + 1 instead of
+        # in line on the engine stream (round 3: 17.7 k -> see profiles/); BBP_BENCH_STREAM_VERIFY_INLINE=1 for the old shape
+        self.vlanes = []
+        if os.environ.get("BBP_BENCH_STREAM_VERIFY_INLINE") != "1":
+            i = 0
+            while ctx.verify_stream(i):
+                self.vlanes.append(torch.cuda.ExternalStream(ctx.verify_stream(i), device=device))
+                i += 1
         self.k = 0
         self.lat_ms, self.failed, self.done_chunks = [], 0, 0
         self.units_per_step = batch
@@ -583,10 +592,22 @@ class StreamWorkload(_Base):
         eng.wait_event(sl["ev_in"])  # the verifier tails
         sl["d_vin"][:, :self.rec] = sl["d_rec"].view(C, self.rec)
         sl["d_vin"][:, self.rec:] = sl["d_vt"].view(C, self.vt)
-        self.ctx.verify_batch_dev(C, N, sl["d_vin"].data_ptr(), sl["d_vent"].data_ptr(), sl["d_st"].data_ptr(), stream)
-        sl["h_rec"].copy_(sl["d_rec"], non_blocking=True)
-        sl["h_st"].copy_(sl["d_st"], non_blocking=True)
-        sl["ev1"].record(eng)
+        if self.vlanes:
+            vs = self.vlanes[self.k % len(self.vlanes)]
+            sl["ev_v"].record(eng)                      # records and verifier rows assembled
+            sl["h_rec"].copy_(sl["d_rec"], non_blocking=True)
+            sl["ev_rec"].record(eng)
+            vs.wait_event(sl["ev_v"])
+            self.ctx.verify_batch_dev(C, N, sl["d_vin"].data_ptr(), sl["d_vent"].data_ptr(), sl["d_st"].data_ptr(), vs.cuda_stream)
+            with torch.cuda.stream(vs):
+                sl["h_st"].copy_(sl["d_st"], non_blocking=True)
+                vs.wait_event(sl["ev_rec"])             # the chunk is done when its flags AND its records are on the host
+                sl["ev1"].record(vs)
+        else:
+            self.ctx.verify_batch_dev(C, N, sl["d_vin"].data_ptr(), sl["d_vent"].data_ptr(), sl["d_st"].data_ptr(), stream)
+            sl["h_rec"].copy_(sl["d_rec"], non_blocking=True)
+            sl["h_st"].copy_(sl["d_st"], non_blocking=True)
+            sl["ev1"].record(eng)
         sl["busy"] = True
         self.k += 1
 
