@@ -512,7 +512,7 @@ static void on_signal(int) {
 
 static void usage(const char* argv0) {
     fprintf(stderr,
-            "usage: %s [-b|--bind-path PATH] [-l|--log-level error|warn|info|debug|trace] [--engine LIB.so] [--device N | --devices 0,1,..]\n"
+            "usage: %s [-b|--bind-path PATH] [-l|--log-level error|warn|info|debug|trace] [--engine LIB.so] [--device N | --devices 0,1,.. | --devices all]\n"
             "          [--window-us US] [--max-batch B] [--max-connections C] [--io-threads T] [--reserve N[,N..]] [--verify-aggregate G]\n",
             argv0);
 }
@@ -539,7 +539,12 @@ int main(int argc, char** argv) {
         else if (a == "--device") devices.assign(1, atoi(val()));
         else if (a == "--devices") {
             devices.clear();
-            for (const char* p = val(); *p;) {
+            const char* list = val();
+            if (strcmp(list, "all") == 0) {  // every visible GPU: bbp_init(-1) = bbp_init_all
+                devices.assign(1, -1);
+                continue;
+            }
+            for (const char* p = list; *p;) {
                 devices.push_back(atoi(p));
                 while (*p && *p != ',') p++;
                 if (*p == ',') p++;
@@ -597,6 +602,12 @@ int main(int argc, char** argv) {
             return 1;
         }
         g_eng.n_devices = devices.size();
+        if (devices.size() == 1 && devices[0] == -1) {  // --devices all: ask the pool how many it found
+            auto pool_size = (decltype(&bbp_pool_size))dlsym(g_eng.so, "bbp_pool_size");
+            g_eng.n_devices = pool_size ? pool_size(g_eng.ctx) : 1;
+            devices.resize(g_eng.n_devices);
+            for (size_t i = 0; i < devices.size(); i++) devices[i] = (int32_t)i;
+        }
         g_eng.set_batching(g_eng.ctx, window_us, max_batch);
         if (g_eng.describe) {  // what the engine runs on; its WARNING lines (hardware queues, memory) at warn level
             static char report[8192];

@@ -84,7 +84,12 @@ int32_t verify_batch_locked(bbp_ctx* ctx, uint32_t B, uint32_t N, uint32_t rec_v
 }  // namespace bbp
 
 extern "C" {
-int32_t bbp_init(int32_t, bbp_ctx** out) {
+int32_t bbp_pool_init(const int32_t* devices, uint32_t n, bbp_ctx** out);
+int32_t bbp_init(int32_t device, bbp_ctx** out) {
+    if (device == -1) {  // "every visible GPU": the stub pretends there are two
+        const int32_t two[2] = {0, 1};
+        return bbp_pool_init(two, 2, out);
+    }
     *out = new bbp_ctx();
     return BBP_OK;
 }

@@ -248,6 +248,30 @@ def test_connections_are_dealt_over_several_device_contexts(built):
     assert m and int(m.group(1)) == 12 and int(m.group(3)) == 12              # window 0, sequential client: one call per request
 
 
+def test_devices_all_serves_from_a_pool_over_every_gpu(built):
+    """--devices all = bbp_init(-1) = bbp_init_all: the stub pretends the node has two GPUs."""
+    built.build_server()
+    stub = built.build_stub_engine()
+    d = tempfile.mkdtemp(prefix="bbp-uds-all-")
+    path, log = os.path.join(d, "sock"), open(os.path.join(d, "log"), "w+")
+    p = subprocess.Popen([built.SERVER_BIN, "-b", path, "--engine", stub, "--devices", "all", "--window-us", "0"], stderr=log)
+    try:
+        for _ in range(200):
+            if os.path.exists(path):
+                break
+            time.sleep(0.02)
+        for i in range(4):
+            s7, pub, toggle = _bid(60 + i, 2)
+            blob = uc.prove(path, s7, pub, toggle)
+            assert uc.verify(path, blob, s7[128:160], s7[160:192], s7[192:224], pub) == b"\x01"
+    finally:
+        p.send_signal(signal.SIGTERM)
+        p.wait(timeout=10)
+    log.seek(0)
+    text = log.read()
+    assert "2 device context(s)" in text and re.search(r"device context 1 \(device 1\): \d+ device calls", text), text[-600:]
+
+
 def test_cli_mirrors_the_reference_flags(built):
     built.build_server()
     p = subprocess.run([built.SERVER_BIN, "-l", "loud"], capture_output=True, text=True)
