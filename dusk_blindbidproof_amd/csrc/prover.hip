@@ -207,7 +207,14 @@ int32_t commit_launch(bbp_ctx* ctx, u32 count, const sc* values, const sc* blind
 }
 
 // encode `per_proof` points per proof from a strided point array into a strided encoding array
-__global__ BBP_LANE_KERNEL void k_encode_strided(u32 count, u32 per_proof, const ge* __restrict__ pts, u32 pts_stride, u32* __restrict__ enc,
+// -DBBP_ENCODE_WAVES=3 (experiment): 179 registers + 384 B of scratch instead of 248 + 32 AGPRs + 144 B -- it then fits on a SIMD beside
+// two accumulate waves (<= 192).  Measured: see DESIGN.md section 9 "round 3".
+#ifdef BBP_ENCODE_WAVES
+#define BBP_ENCODE_ATTR __attribute__((amdgpu_waves_per_eu(BBP_ENCODE_WAVES, BBP_ENCODE_WAVES)))
+#else
+#define BBP_ENCODE_ATTR
+#endif
+__global__ BBP_LANE_KERNEL BBP_ENCODE_ATTR void k_encode_strided(u32 count, u32 per_proof, const ge* __restrict__ pts, u32 pts_stride, u32* __restrict__ enc,
                                  u32 enc_stride_words, u32 enc_off_words) {
     BBP_THIN_PRIO();
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
