@@ -97,6 +97,9 @@ struct bbp_ctx {
     bool sort_lds_attr1 = false;  // ... and that of the generator-fold instance
     int debug_corrupt = 0;      // bbp_debug_corrupt_scratch: poison the next MSM launch's sorted scratch (tests)
     int fold_half_from = 512;  // MSM launches with at least this many MSMs fold on half a wavefront per MSM (msm.hip k_msm_fold_half; BBP_FOLD_HALF_FROM)
+    int tail_small_below = 65;    // heavy stages of fewer proofs than this keep ALL eleven IPA rounds on the fixed-base MSM kernels: a short chain of
+                                  // launches that fill the GPU by splitting beats the generator fold + table + tail kernels when latency is what counts
+                                  // (one proof 24.7 -> 23.5 ms, 8 proofs 26.2 -> 23.8, 64 proofs 30.2 -> 29.3; 256 proofs 38.9 -> 40.9: not there).  BBP_TAIL_SMALL_BELOW
     int tail_round = bbp::FOLD_ROUND;  // first IPA round run on explicit folded generators (BBP_TAIL_ROUND=12 disables)
     int serial_lds = 160 * 1024;  // LDS the one-lane-per-proof opening kernels reserve to keep their CU to themselves (BBP_SERIAL_LDS, 0 = off)
     // TranscriptRng draw chain on 25 lanes per sponge (k_open_bulk) instead of one lane per proof.  The cooperative form is bound
@@ -106,6 +109,7 @@ struct bbp_ctx {
     // of at most rng_coop_below proofs (768; with four wavefronts per CU a 512-proof chain takes ~15 ms on 64 CUs).  BBP_RNG_COOP=0 / 1 forces, BBP_RNG_COOP_BELOW, BBP_RNG_BLOCK tune.
     int rng_coop = -1;
     int rng_coop_below = 768;
+    int rng_dpp = 1;              // cooperative chain on one wavefront per proof with DPP / permlane-swap theta (k_open_bulk8); BBP_RNG_DPP=0: the 25-lane ds_bpermute form (k_open_bulk)
     int rng_block = 0;            // threads per workgroup of k_open_bulk (BBP_RNG_BLOCK); 0 = by batch size: 64 (one wavefront = two proofs per reserved CU) up to 128 proofs, 128 up to 256, 256 above
     int serial_block = 64;        // threads per workgroup of those kernels: 256 = one serial wave per SIMD of the reserved CU (BBP_SERIAL_BLOCK)
     std::map<const void*, int> serial_attr;

@@ -383,6 +383,135 @@ __global__ void k_open_bulk(u32 B, u32 rng_blocks, u32 n1, u32 count, merlin_tra
     if (live && l == 0) T->cur_flags = BBP_FLAG_I | BBP_FLAG_A | BBP_FLAG_C;
 }
 
+// ---- cooperative Keccak, second form (round 3): ONE sponge per wavefront, theta without the LDS crossbar ---------------------------
+// State word (x, y) lives in lane 8 y + x (x, y < 5: lanes 0..36 with gaps; every other lane holds zero and stays zero), so a
+// DPP row (16 lanes) holds two planes.  Column parity: one row_ror:8 XOR joins the two planes of a row, v_permlane16_swap /
+// v_permlane32_swap (gfx950) join the four rows -- seven VALU instructions per 32-bit half instead of eight ds_bpermute and a
+// wait; theta's two neighbours are DPP row shifts inside the 8-lane group (the wrap from x = 4 to x = 0 through a second,
+// bank-masked move).  Only the rho-pi-chi gather still crosses the wavefront through ds_bpermute (6 per round instead of 18):
+// one LDS round trip per round instead of three.  Rho is two v_alignbit_b32 with a lane-constant shift after a lane-constant
+// word swap.  The bytes are the same as the 25-lane form's and the single-lane chain's (every parity test goes through it).
+#ifndef BBP_COOP8_UNROLL
+#define BBP_COOP8_UNROLL 24
+#endif
+struct coop8_lane {
+    int s0, s1, s2;      // ds_bpermute byte addresses of B[x][y], B[x+1][y], B[x+2][y]
+    u32 sh;              // v_alignbit shift of the rho rotation
+    bool swap, x0, first;  // rho: swap the halves first; lane holds column 0; lane holds word (0, 0)
+    u32 live;            // all ones in the 25 state lanes
+};
+
+__device__ __forceinline__ coop8_lane coop8_setup(u32 L) {
+    const u32 x = L & 7u, y = L >> 3;
+    const bool live = x < 5 && y < 5;
+    const u32 RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+    coop8_lane c;
+    // pi: B[X][Y] is the rotated word of source (x, y) = ((X + 3 Y) mod 5, X); idle lanes read themselves (zero)
+    auto src = [&](u32 X) { return live ? 4 * (int)(8 * X + (X + 3 * y) % 5) : 4 * (int)L; };
+    c.s0 = src(x % 5);
+    c.s1 = src((x + 1) % 5);
+    c.s2 = src((x + 2) % 5);
+    const u32 rot = live ? RHO[(x + 5 * y) % 25] : 0, r = rot & 31u;
+    c.swap = (rot >= 32) != (r == 0);  // alignbit by 0 is itself a swap of the halves
+    c.sh = (32u - r) & 31u;
+    c.x0 = x == 0;
+    c.first = L == 0;
+    c.live = live ? ~0u : 0u;
+    return c;
+}
+
+#define BBP_DPP_ROW_SHL(n) (0x100 + (n))
+#define BBP_DPP_ROW_SHR(n) (0x110 + (n))
+#define BBP_DPP_ROW_ROR(n) (0x120 + (n))
+// XOR over the five planes of both halves of the state words, in every lane of the column (lane & 7).  The two halves share the
+// permlane swaps: after the first one a single register carries the low half's row pairs in even rows and the high half's in odd rows.
+__device__ __forceinline__ void coop8_colpar(u32 lo, u32 hi, u32& cl, u32& ch) {
+    const u32 tl = lo ^ (u32)__builtin_amdgcn_update_dpp(0, (int)lo, BBP_DPP_ROW_ROR(8), 0xf, 0xf, true);  // the row's two planes
+    const u32 th = hi ^ (u32)__builtin_amdgcn_update_dpp(0, (int)hi, BBP_DPP_ROW_ROR(8), 0xf, 0xf, true);
+    const auto p = __builtin_amdgcn_permlane16_swap(tl, th, false, false);  // (tl.r0, th.r0, tl.r2, th.r2), (tl.r1, th.r1, tl.r3, th.r3)
+    const u32 x = p[0] ^ p[1];                                              // rows: A_l, A_h, B_l, B_h  (A = r0 ^ r1, B = r2 ^ r3)
+    const auto q = __builtin_amdgcn_permlane32_swap(x, x, false, false);    // (A_l, A_h, A_l, A_h), (B_l, B_h, B_l, B_h)
+    const u32 y = q[0] ^ q[1];                                              // rows: L, H, L, H
+    const auto r = __builtin_amdgcn_permlane16_swap(y, y, false, false);    // (L, L, L, L), (H, H, H, H)
+    cl = r[0];
+    ch = r[1];
+}
+__device__ __forceinline__ u32 coop8_next(u32 v) {  // column x + 1 (mod 5) of the same plane
+    const int a = __builtin_amdgcn_update_dpp(0, (int)v, BBP_DPP_ROW_SHL(1), 0xf, 0xf, true);
+    return (u32)__builtin_amdgcn_update_dpp(a, (int)v, BBP_DPP_ROW_SHR(4), 0xf, 0xa, false);  // lanes 4..7 / 12..15 of a row: x = 4 reads x = 0
+}
+__device__ __forceinline__ u32 coop8_prev(u32 v, bool x0) {  // column x - 1 (mod 5) of the same plane
+    const u32 w = (u32)__builtin_amdgcn_update_dpp(0, (int)v, BBP_DPP_ROW_SHL(4), 0xf, 0xf, true);  // x = 0 reads x = 4
+    const u32 a = (u32)__builtin_amdgcn_update_dpp(0, (int)v, BBP_DPP_ROW_SHR(1), 0xf, 0xf, true);
+    return x0 ? w : a;
+}
+
+__device__ __forceinline__ void coop8_keccak_f(u32& lo, u32& hi, const coop8_lane& c) {
+    const u64 RC[24] = {0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808Aull, 0x8000000080008000ull,
+                        0x000000000000808Bull, 0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull,
+                        0x000000000000008Aull, 0x0000000000000088ull, 0x0000000080008009ull, 0x000000008000000Aull,
+                        0x000000008000808Bull, 0x800000000000008Bull, 0x8000000000008089ull, 0x8000000000008003ull,
+                        0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800Aull, 0x800000008000000Aull,
+                        0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+#pragma unroll BBP_COOP8_UNROLL
+    for (int r = 0; r < 24; r++) {
+        // theta
+        u32 cl, ch;
+        coop8_colpar(lo, hi, cl, ch);
+        const u32 ml = coop8_prev(cl, c.x0), mh = coop8_prev(ch, c.x0), pl = coop8_next(cl), ph = coop8_next(ch);
+        lo ^= (ml ^ __builtin_amdgcn_alignbit(pl, ph, 31)) & c.live;  // D = C[x-1] ^ rotl(C[x+1], 1); the idle planes must stay zero
+        hi ^= (mh ^ __builtin_amdgcn_alignbit(ph, pl, 31)) & c.live;
+        // rho at the source
+        const u32 a = c.swap ? hi : lo, b = c.swap ? lo : hi;  // (low, high) after the optional rotation by 32
+        const u32 rl = __builtin_amdgcn_alignbit(a, b, c.sh), rh = __builtin_amdgcn_alignbit(b, a, c.sh);
+        // pi and chi's two neighbours in one gather phase
+        const u32 b0l = (u32)__builtin_amdgcn_ds_bpermute(c.s0, (int)rl), b0h = (u32)__builtin_amdgcn_ds_bpermute(c.s0, (int)rh);
+        const u32 b1l = (u32)__builtin_amdgcn_ds_bpermute(c.s1, (int)rl), b1h = (u32)__builtin_amdgcn_ds_bpermute(c.s1, (int)rh);
+        const u32 b2l = (u32)__builtin_amdgcn_ds_bpermute(c.s2, (int)rl), b2h = (u32)__builtin_amdgcn_ds_bpermute(c.s2, (int)rh);
+        // chi as one bit-select: b1 ? b0 : b0 ^ b2; iota in lane 0
+        lo = ((b1l & b0l) | (~b1l & (b0l ^ b2l))) ^ (c.first ? (u32)RC[r] : 0u);
+        hi = ((b1h & b0h) | (~b1h & (b0h ^ b2h))) ^ (c.first ? (u32)(RC[r] >> 32) : 0u);
+    }
+}
+
+// rng waves: one proof per wavefront (state lanes 8 y + x); witness blocks as in k_open_bulk
+__global__ void k_open_bulk8(u32 B, u32 rng_blocks, u32 n1, u32 count, merlin_transcript* __restrict__ rng, u32* __restrict__ raw, u32 m,
+                             u32 n_cst, const u32* __restrict__ w_terms, const u32* __restrict__ w_loff, const u32* __restrict__ w_roff,
+                             const sc* __restrict__ cst_all, const sc* __restrict__ v_all, sc* __restrict__ ai1_all, sc* __restrict__ ao1_all) {
+    if (blockIdx.x >= rng_blocks) {
+        const u32 p = (blockIdx.x - rng_blocks) * blockDim.x + threadIdx.x;
+        if (p < B) witness_gates_lane(p, m, n1, n_cst, w_terms, w_loff, w_roff, cst_all, v_all, ai1_all, ao1_all);
+        return;
+    }
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 g = t >> 6, L = t & 63u;
+    const coop8_lane c = coop8_setup(L);
+    const bool live = g < B && c.live != 0;
+    const u32 p = g < B ? g : B - 1;
+    const u32 word = (L & 7u) + 5 * (L >> 3);  // index of this lane's state word (state lanes only)
+    merlin_transcript* T = rng + p;
+    const u64 a0 = c.live ? T->st[word % 25] : 0;
+    u32 lo = (u32)a0, hi = (u32)(a0 >> 32);
+    // per-draw constants (keccak.h merlin_rng_fill64_bulk): st[8] ^= .., st[9] ^= .., st[20] ^= ..
+    const u64 konst = !c.live ? 0ull : word == 8 ? 0x0741000000401200ull : word == 9 ? 0x0000000000000447ull : word == 20 ? 0x8000000000000000ull : 0ull;
+    const bool rate = c.live && word < 8;
+    u32* out = raw + (size_t)p * (3 + 2 * (size_t)n1) * 16 + 16 + 2 * (word & 7u);  // draw 0 was written by the prefix kernel
+    for (u32 d = 0; d < count; d++) {
+        lo ^= (u32)konst;
+        hi ^= (u32)(konst >> 32);
+        coop8_keccak_f(lo, hi, c);
+        if (rate) {
+            if (live) {
+                out[(size_t)d * 16] = lo;
+                out[(size_t)d * 16 + 1] = hi;
+            }
+            lo = hi = 0;
+        }
+    }
+    if (live) T->st[word] = ((u64)hi << 32) | lo;
+    if (live && c.first) T->cur_flags = BBP_FLAG_I | BBP_FLAG_A | BBP_FLAG_C;
+}
+
 // draw j of proof p -> its scalar slot: 0 -> ai1[0], 1 -> ao1[0], 2 -> s1[0], j >= 3 -> s1[1 + (j - 3)]
 __global__ void k_reduce_draws(u32 B, u32 n1, const u32* __restrict__ raw, sc* __restrict__ ai1, sc* __restrict__ ao1, sc* __restrict__ s1) {
     const u32 per = 3 + 2 * n1;
@@ -1318,14 +1447,22 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
                    bd.tr, bd.rng, c.n_cst, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v, bd.ai1, bd.ao1, 1u);
             // bulk: 32 lanes per proof for the draw chain + one lane per proof for the witness, in one launch of `cblk`-thread
             // workgroups that keep their CU to themselves (LDS hog): cblk / 32 proofs per rng workgroup
-            if ((rc = serial_lds_bytes(ctx, (const void*)k_open_bulk))) return rc;
             // workgroup size: one wavefront (two proofs) per reserved CU is the fastest chain, but at 256 proofs that reserves 128 CUs
             // under the other in-flight calls' heavy stages; two wavefronts per CU there (measured 11.3 k -> 12.5 k proofs/s back to back),
             // four above 256 proofs (384: 12.8 k -> 14.8 k, 512: 14.6 k -> 16.5 k against the single-lane chain)
             const u32 cblk = ctx->rng_block > 0 ? (u32)ctx->rng_block : (B <= 128 ? 64u : B <= 256 ? 128u : 256u);
-            const u32 nb_rng = cdiv(B * 32, cblk), nb_wit = cdiv(B, cblk);
-            LAUNCH_LDS(ctx, TAG_RNG, k_open_bulk, nb_rng + nb_wit, cblk, hog, s, B, nb_rng, n1, 2 + 2 * n1, bd.rng, (u32*)ctx->raw[sidx].p, m,
-                       c.n_cst, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v, bd.ai1, bd.ao1);
+            if (ctx->rng_dpp) {
+                // one proof per wavefront (k_open_bulk8): the same number of proofs per reserved CU needs twice the lanes
+                if ((rc = serial_lds_bytes(ctx, (const void*)k_open_bulk8))) return rc;
+                const u32 cblk8 = 2 * cblk > 1024u ? 1024u : 2 * cblk, nb_rng = cdiv(B * 64, cblk8), nb_wit = cdiv(B, cblk8);
+                LAUNCH_LDS(ctx, TAG_RNG, k_open_bulk8, nb_rng + nb_wit, cblk8, hog, s, B, nb_rng, n1, 2 + 2 * n1, bd.rng, (u32*)ctx->raw[sidx].p, m,
+                           c.n_cst, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v, bd.ai1, bd.ao1);
+            } else {
+                if ((rc = serial_lds_bytes(ctx, (const void*)k_open_bulk))) return rc;
+                const u32 nb_rng = cdiv(B * 32, cblk), nb_wit = cdiv(B, cblk);
+                LAUNCH_LDS(ctx, TAG_RNG, k_open_bulk, nb_rng + nb_wit, cblk, hog, s, B, nb_rng, n1, 2 + 2 * n1, bd.rng, (u32*)ctx->raw[sidx].p, m,
+                           c.n_cst, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v, bd.ai1, bd.ao1);
+            }
         }
         LAUNCH(ctx, TAG_RNG, k_reduce_draws, cdiv((u32)(B * n_draws), 128), 128, s, B, n1, (const u32*)ctx->raw[sidx].p, bd.ai1, bd.ao1, bd.s1);
         BBP_HIP_TRY(ctx, hipEventRecord(ctx->ev_open[par], s));
@@ -1418,7 +1555,8 @@ static int32_t prove_heavy(bbp_ctx* ctx, const CircuitDev& c, const BatchDev& bd
     LAUNCH(ctx, TAG_TRANSCRIPT, k_tr_ux, cdiv(B, 64), 64, s, B, m, n1, bd.enc, bd.wv, bd.vb, bd.ai1, bd.ao1, bd.s1, bd.tr, bd.misc);
     LAUNCH(ctx, TAG_POLY, k_lrvec, cdiv(B * 2048, 128), 128, s, B, n1, bd.l1, bd.r0, bd.r1, bd.r3, bd.ao1, bd.s1, bd.ypow, bd.yipow, bd.misc,
            bd.a, bd.b, bd.g, bd.h);
-    const u32 tail_from = (u32)ctx->tail_round;  // FOLD_ROUND (7), or 12 = never leave the fixed-base formulation
+    // FOLD_ROUND (7), or 12 = never leave the fixed-base formulation (small heavy stages: context.h tail_small_below)
+    const u32 tail_from = B < (u32)(ctx->tail_small_below > 0 ? ctx->tail_small_below : 0) ? 12u : (u32)ctx->tail_round;
     for (u32 r = 1; r <= 11 && r < tail_from; r++) {
         if (r > 1) LAUNCH(ctx, TAG_TRANSCRIPT, k_ipa_challenge, cdiv(B, 64), 64, s, B, r - 1, m, bd.enc, bd.tr, bd.misc);
         LAUNCH(ctx, TAG_IPA_SCALARS, k_ipa_round, B, IPA_BLK, s, r, n1, bd.misc, bd.a, bd.b, bd.g, bd.h, bd.lr);

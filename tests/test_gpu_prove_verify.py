@@ -384,6 +384,9 @@ def test_calls_from_different_streams_are_serialised(ctx, oc, bbp):
     {"BBP_RNG_COOP": "0"},                                      # TranscriptRng draw chain on one lane per proof (round-1 path)
     {"BBP_RNG_COOP": "1", "BBP_RNG_BLOCK": "64", "BBP_SERIAL_LDS": "0"},  # cooperative rng forced: one wavefront (two proofs) per workgroup, not fenced
     {"BBP_RNG_COOP": "1", "BBP_RNG_BLOCK": "1024"},             # cooperative rng forced: 32 proofs per reserved CU
+    {"BBP_RNG_COOP": "1", "BBP_RNG_DPP": "0"},                  # ... in its 25-lane ds_bpermute form (two proofs per wavefront)
+    {"BBP_RNG_COOP": "1", "BBP_RNG_DPP": "0", "BBP_RNG_BLOCK": "64", "BBP_SERIAL_LDS": "0"},
+    {"BBP_TAIL_SMALL_BELOW": "0", "BBP_SLICES": "1"},           # small heavy stages take the folded-generator tail as well
     {"BBP_FOLD_HALF_FROM": "1"},                                # every MSM launch folds on half a wavefront per MSM
     {"BBP_FOLD_HALF_FROM": "1000000"},                          # ... and none does (128 lanes per MSM)
 ])
