@@ -173,6 +173,7 @@ extern "C" int32_t bbp_pool_init(const int32_t* devices, uint32_t n_devices, bbp
         const char* e = getenv("BBP_BATCH_STAGGER_US");
         c->set_stagger(e ? (uint32_t)atoi(e) : 35000u);
         c->set_leaders(1, bbp_ctx::VLANES);
+        if (const char* lw = getenv("BBP_BATCH_LOPSIDED_WAIT")) c->set_lopsided_wait(atoi(lw) != 0);
         if (const char* pl = getenv("BBP_BATCH_PROVE_LEADERS")) c->set_leaders(0, atoi(pl));
         const char* ss = getenv("BBP_BATCH_STAGGER_SMALL_US");
         c->set_small_stagger(256, ss ? (uint32_t)atoi(ss) : 15000u);

@@ -143,6 +143,7 @@ static int32_t init_body(int32_t device, bbp_ctx** out) {
         const char* e = getenv("BBP_BATCH_STAGGER_US");
         static_cast<Combiner*>(ctx->combiner)->set_stagger(e ? (uint32_t)atoi(e) : 35000u);
         static_cast<Combiner*>(ctx->combiner)->set_leaders(1, bbp_ctx::VLANES);  // one verification batch in flight per verifier lane
+        if (const char* lw = getenv("BBP_BATCH_LOPSIDED_WAIT")) static_cast<Combiner*>(ctx->combiner)->set_lopsided_wait(atoi(lw) != 0);
         if (const char* pl = getenv("BBP_BATCH_PROVE_LEADERS")) static_cast<Combiner*>(ctx->combiner)->set_leaders(0, atoi(pl));  // prove batches in flight (default 2; the host path has three slots)
         const char* ss = getenv("BBP_BATCH_STAGGER_SMALL_US");  // behind a batch of at most 256 proofs (cooperative rng chain: a ~13 ms opening stage)
         static_cast<Combiner*>(ctx->combiner)->set_small_stagger(256, ss ? (uint32_t)atoi(ss) : 15000u);

@@ -79,6 +79,7 @@ class Combiner {
     void set_stagger(uint32_t us);
     // batch threads per target for requests of `kind` (0 prove, 1 verify): as many verification batches in flight as the engine has verifier lanes
     void set_leaders(int kind, int n);
+    void set_lopsided_wait(bool on);
     // behind a prove batch of at most `small_batch` proofs the stagger is `us` instead (their opening stage is shorter)
     void set_small_stagger(uint32_t small_batch, uint32_t us);
     // Behind a busy device a prove batch leaves only when the queue has stopped growing for `quiet_us`, at most `cap_us` after its
@@ -130,6 +131,7 @@ class Combiner {
     int max_leaders_locked(int kind) const { return leaders_[kind] * (int)(targets_.empty() ? 1 : targets_.size()); }
     uint32_t window_us_ = 0, max_batch_ = 4096, stagger_us_ = 0, split_min_ = 0, quiet_us_ = 300, quiet_cap_us_ = 0, open_us_ = 40000;
     int32_t hold_margin_us_ = -1;
+    bool lopsided_ = true;  // set_lopsided_wait: a few requests behind one large batch wait for its callers (closed-loop clients)
     uint32_t small_batch_ = 0, small_stagger_us_ = 0xffffffffu;
     double per_proof_us_ = 48.0;
     uint64_t n_calls_ = 0, n_requests_ = 0;
