@@ -114,10 +114,13 @@ struct bbp_ctx {
     int serial_block = 64;        // threads per workgroup of those kernels: 256 = one serial wave per SIMD of the reserved CU (BBP_SERIAL_BLOCK)
     std::map<const void*, int> serial_attr;
     int stagger_mode = 0;  // 0: slices start together, 1: next slice starts after this slice's first MSM, 3: after its third (BBP_STAGGER)
-    static constexpr int PROVE_BUFS = 3;  // prover batch buffers in rotation (call k uses buffer k % 3)
-    hipEvent_t ev_open[PROVE_BUFS] = {nullptr, nullptr, nullptr}, ev_done[PROVE_BUFS] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_entry[PROVE_BUFS] = {nullptr, nullptr, nullptr};  // caller's stream at entry of a prove call: out_dev is not written before it
-    bool ev_done_valid[PROVE_BUFS] = {false, false, false}, ev_open_valid[PROVE_BUFS] = {false, false, false};
+#ifndef BBP_PROVE_BUFS
+#define BBP_PROVE_BUFS 5
+#endif
+    static constexpr int PROVE_BUFS = BBP_PROVE_BUFS;  // prover batch buffers in rotation (call k of the small-batch path uses buffer k % PROVE_BUFS; large batches alternate between 0 and 1)
+    hipEvent_t ev_open[PROVE_BUFS] = {}, ev_done[PROVE_BUFS] = {};
+    hipEvent_t ev_entry[PROVE_BUFS] = {};  // caller's stream at entry of a prove call: out_dev is not written before it
+    bool ev_done_valid[PROVE_BUFS] = {}, ev_open_valid[PROVE_BUFS] = {};
     int verify_overlap = 1;                              // BBP_VERIFY_OVERLAP: lane 0's variable-base kernels on a side stream (no measurable difference with four lanes)
     // BBP_VERIFY_SERIAL_ACC=1: the verifier lanes' MSM accumulate launches are chained by events so that no two of them are
     // co-resident (each then runs beside the other lanes' thin front-end kernels only).  Helps two lanes that share hardware queues

@@ -1410,7 +1410,7 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
     // is then cut in at most two slices so that no more than four queues are active (a fifth costs ~7 %).
     const bool dual = B < (u32)(ctx->dual_open_below > 0 ? ctx->dual_open_below : 0);
     const int sidx = dual ? (int)(call & 1u) : 0;
-    const int par = dual ? (int)(call % (u32)bbp_ctx::PROVE_BUFS) : (int)(call & 1u);  // two openings in flight need a third buffer
+    const int par = dual ? (int)(call % (u32)bbp_ctx::PROVE_BUFS) : (int)(call & 1u);  // three heavy-stage chains + two openings in flight: five buffers.  (With three, call k's opening had to wait for call k-3's heavy stage -- the chain that runs on the very stream call k's heavy stage is queued on -- and every chain stream idled for an opening stage per call: 24 % at 256 proofs per call.)
     if (dual && !ctx->side2) BBP_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side2, hipStreamNonBlocking));
     BatchDev bd;
     if ((rc = batch_reserve(ctx, B, c, bd, par))) return rc;

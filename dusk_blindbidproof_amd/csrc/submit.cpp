@@ -108,6 +108,10 @@ size_t Combiner::pick_target_locked(int kind) {
     return best;
 }
 
+Combiner::Combiner() {
+    if (const char* p = getenv("BBP_BATCH_LOG")) log_ = fopen(p, "a");
+}
+
 Combiner::~Combiner() {
     {
         std::lock_guard<std::mutex> lk(mu_);
@@ -118,6 +122,7 @@ Combiner::~Combiner() {
         L.cv_window.notify_all();
     }
     for (auto& t : threads_) t.join();
+    if (log_) fclose(log_);
 }
 
 // queue a request; start the batch threads with the first one (two per target: a second batch is prepared and its opening stage
@@ -288,9 +293,17 @@ void Combiner::thread_main(int kind) {
             targets_[ti].last_size = (uint32_t)batch.size();
         }
         bbp_ctx* const where = targets_[ti].ctx;
+        const auto t_batch = std::chrono::steady_clock::now();
+        const size_t q_left = q_.size();
+        const int inflight_before = proving ? targets_[ti].prove_inflight - 1 : 0;
         lk.unlock();
         run_batch(where, batch);
         lk.lock();
+        if (log_) {  // BBP_BATCH_LOG: start (ms since the combiner was made), duration, kind, target, size, prove batches already in flight, queue left behind
+            const auto t_end = std::chrono::steady_clock::now();
+            fprintf(log_, "%.2f %.2f %s %zu %zu %d %zu\n", std::chrono::duration<double, std::milli>(t_batch - t0_).count(),
+                    std::chrono::duration<double, std::milli>(t_end - t_batch).count(), proving ? "prove" : "verify", ti, batch.size(), inflight_before, q_left);
+        }
         if (proving) {
             targets_[ti].prove_inflight--;
             targets_[ti].last_done = std::chrono::steady_clock::now();

@@ -15,6 +15,8 @@
 // needs, since it cannot park a thread per request); the blocking bbp_prove / bbp_verify are the same path plus a wait.
 #pragma once
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include <chrono>
 #include <condition_variable>
@@ -62,7 +64,7 @@ class Combiner {
     // queue and return: r->on_done fires when the batch that carried it is done.  false = the combiner has no thread to run it
     // (thread creation failed): nothing was queued, the hook will not fire
     bool submit_async(bbp_ctx* ctx, Request* r);
-    Combiner() = default;
+    Combiner();
     ~Combiner();  // runs whatever is still queued (every callback fires, every waiter returns), then joins the threads
     Combiner(const Combiner&) = delete;
     Combiner& operator=(const Combiner&) = delete;
@@ -136,6 +138,8 @@ class Combiner {
     double per_proof_us_ = 48.0;
     uint64_t n_calls_ = 0, n_requests_ = 0;
     uint32_t max_seen_ = 0;
+    FILE* log_ = nullptr;  // BBP_BATCH_LOG=path: one line per batch (tools/batch_log.py)
+    std::chrono::steady_clock::time_point t0_ = std::chrono::steady_clock::now();
 };
 
 }  // namespace bbp
