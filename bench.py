@@ -246,7 +246,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default=os.environ.get("BBP_BENCH_WORKLOAD", "prove"))
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--items", type=int, default=8, help="bid-list length N (SURVEY.md 8d default 8)")

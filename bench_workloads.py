@@ -259,6 +259,8 @@ class ProveWorkload(_Base):
         self.ent_dev = _to_dev(torch, device, b"".join(self.ents))
         self.rec = bbp.record_size(items)
         self.out_dev = torch.zeros(batch * self.rec, dtype=torch.uint8, device=device)
+        if hasattr(ctx, "reserve") and not os.environ.get("BBP_BENCH_NO_RESERVE"):
+            ctx.reserve(batch, items)  # bbp_reserve: every buffer of every schedule sized before the clock starts (what a server does at start-up)
         self.units_per_step = batch
         n1 = 1442 + 3 * items
         commit_terms = (1 + 2 * n1) * 2 + (1 + n1)

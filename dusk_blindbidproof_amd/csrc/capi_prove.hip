@@ -762,6 +762,12 @@ extern "C" int32_t bbp_reserve(bbp_ctx* ctx, uint32_t max_batch, uint32_t N) {
         for (int k = 0; k < bbp_ctx::IO_SLOTS && rc == BBP_OK; k++) rc = prove_batch_host(ctx, B, N, in.data(), ent.data(), out.data(), st.data());
         const uint32_t small = B < 1023 ? B : 1023;
         for (int k = 0; k < bbp_ctx::PROVE_BUFS && rc == BBP_OK && B >= 1024; k++) rc = prove_batch_host(ctx, small, N, in.data(), ent.data(), out.data(), st.data());
+        // ... and the shape a caller with several calls in flight gets (prover.hip "deep"): whole calls of B in rotation, five buffers
+        if (B >= 1024 && ctx->slices > 1 && ctx->rotate_deep_max > 0 && B <= (uint32_t)ctx->rotate_deep_max) {
+            struct Reset { bool& b; ~Reset() { b = false; } } reset{ctx->force_deep};
+            ctx->force_deep = true;
+            for (int k = 0; k < bbp_ctx::PROVE_BUFS && rc == BBP_OK; k++) rc = prove_batch_host(ctx, B, N, in.data(), ent.data(), out.data(), st.data());
+        }
         for (int k = 0; k < bbp_ctx::IO_VSLOTS && rc == BBP_OK; k++) rc = verify_batch_host(ctx, B, N, 0, vin.data(), st.data());
         return rc;
     });

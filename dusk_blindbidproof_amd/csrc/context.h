@@ -87,6 +87,16 @@ struct bbp_ctx {
     hipStream_t side2 = nullptr;           // second opening stream: batches too small to fill three heavy slices alternate between the two
     int varbase_lanes = 65536;             // lanes the verifier's variable-base kernel is launched with (BBP_VARBASE_LANES): ~1 wave per SIMD
     int rotate_below = 1023;               // batches of at most this many proofs run their heavy stage unsliced on a rotating internal stream (BBP_ROTATE_BELOW, 0 = never)
+    int rotate_deep_max = 4096;            // calls of up to this many proofs issued while two or more earlier prove calls are still in flight take the rotating path too (BBP_ROTATE_DEEP_MAX, 0 = never; never with BBP_SLICES=1)
+    bool deep_mode = false, force_deep = false;  // (state of that rule; force_deep: bbp_reserve warming the rotating path's buffers)
+    int deep_idle_seen = 0;
+    static constexpr int CALL_RING = 8;
+    hipEvent_t ev_call[CALL_RING] = {};    // completion of the last CALL_RING prove calls (how many are still in flight)
+    bool ev_call_valid[CALL_RING] = {};
+    int deep_from = 3;                     // earlier prove calls in flight that switch a caller to the rotating path (BBP_ROTATE_DEEP_FROM)
+    int mixed_from = 512;                  // ... but a batch of at least this many proofs that arrives while a sliced heavy stage is in flight takes the sliced path too (BBP_ROTATE_MIXED_FROM, 0 = never)
+    int last_prove_par = -1;               // buffer of the last prove call (last_par is also set by the verifier lanes)
+    bool last_sliced = false;              // the last prove call's heavy stage ran as slices on the caller's stream + lanes
     int dual_open_below = 1024;            // batches smaller than this open on alternating streams (BBP_DUAL_OPEN_BELOW, 0 = never)
     static constexpr int MAX_SLICES = 4;   // heavy-stage slices of one batch, one stream each (slice 0 = caller's stream)
     hipStream_t lane[MAX_SLICES] = {nullptr, nullptr, nullptr, nullptr};

@@ -1408,7 +1408,33 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
     // Batches too small to fill three heavy slices are bound by the opening stage (its rng chain lasts ~40 ms whatever the
     // batch size), so their openings alternate between two streams and two of them are in flight at once; the heavy stage
     // is then cut in at most two slices so that no more than four queues are active (a fifth costs ~7 %).
-    const bool dual = B < (u32)(ctx->dual_open_below > 0 ? ctx->dual_open_below : 0);
+    // ... unless a SLICED heavy stage (a batch of 1024 or more) is still on the device and this batch is not small: its unsliced
+    // chain would run beside that batch's three slices -- a fourth and fifth busy heavy stream -- and both lose.  Two host threads
+    // alternating 870- and 2202-proof batches (what the combiner's two batch threads settle into under closed-loop load): 18.8 k
+    // proofs/s that way, 21.6 k with the 870 sliced and stream-ordered behind the 2202 like any large batch (tools/host_pairs.py).
+    // A caller that keeps TWO OR MORE earlier prove calls in flight (device API, calls enqueued without host synchronisation) is
+    // better served by whole calls in rotation than by slices of one call, whatever the batch size: three unsliced chains of three
+    // calls, each with its opening stage behind it, out of phase by construction (five buffers: context.h).  1024-proof calls back
+    // to back: 48.8 ms per call sliced, 45.9-46.7 in rotation (21.0 k -> 21.9-22.3 k proofs/s); 2048: 90.4 -> 87.2 ms.  With at most
+    // one earlier call in flight (the host-pointer path under the combiner's two batch threads) slices win: 21.4 k against 17.9 k.
+    int inflight = 0;  // earlier prove calls still on the device: a ring of per-call completion events (the buffers' own events say
+                       // nothing beyond two calls while the calls are sliced: those alternate between two buffers)
+    for (int k = 0; k < bbp_ctx::CALL_RING; k++)
+        if (ctx->ev_call_valid[k] && hipEventQuery(ctx->ev_call[k]) == hipErrorNotReady) inflight++;
+    // (sticky: entered with two earlier calls in flight, left after six calls in a row that found fewer -- a caller that
+    // synchronises now and then, bench.py's barriers around its timed loop, does not fall back to slices for the calls that refill
+    // its pipeline; the combiner's two batch threads never enter, and leave within six batches if a third caller once made them)
+    if (inflight >= ctx->deep_from) {
+        ctx->deep_mode = true;
+        ctx->deep_idle_seen = 0;
+    } else if (++ctx->deep_idle_seen >= 6) {
+        ctx->deep_mode = false;
+    }
+    const bool deep = (ctx->deep_mode || ctx->force_deep) && ctx->slices > 1 && ctx->rotate_deep_max > 0 && B <= (u32)ctx->rotate_deep_max;
+    bool behind_sliced = false;
+    if (!deep && ctx->mixed_from > 0 && B >= (u32)ctx->mixed_from && ctx->last_sliced && ctx->last_prove_par >= 0 && ctx->ev_done_valid[ctx->last_prove_par])
+        behind_sliced = hipEventQuery(ctx->ev_done[ctx->last_prove_par]) == hipErrorNotReady;
+    const bool dual = !behind_sliced && (deep || B < (u32)(ctx->dual_open_below > 0 ? ctx->dual_open_below : 0));
     const int sidx = dual ? (int)(call & 1u) : 0;
     const int par = dual ? (int)(call % (u32)bbp_ctx::PROVE_BUFS) : (int)(call & 1u);  // three heavy-stage chains + two openings in flight: five buffers.  (With three, call k's opening had to wait for call k-3's heavy stage -- the chain that runs on the very stream call k's heavy stage is queued on -- and every chain stream idled for an opening stage per call: 24 % at 256 proofs per call.)
     if (dual && !ctx->side2) BBP_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side2, hipStreamNonBlocking));
@@ -1479,7 +1505,9 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
     // after the other: 31 ms per 256-proof call whatever else is tuned.  Such calls therefore run their heavy stage UNSLICED on
     // one of the three internal slice streams in rotation (own scratch slot each, like slices): up to three calls' chains in
     // flight; the caller's stream only waits for the result.
-    const bool rotate = dual && ctx->rotate_below > 0 && B <= (u32)ctx->rotate_below;
+    const bool rotate = dual && ((ctx->rotate_below > 0 && B <= (u32)ctx->rotate_below) || (deep && B > (u32)ctx->rotate_below));
+    static const bool trace_calls = getenv("BBP_TRACE_PROVE") != nullptr;
+    if (trace_calls) fprintf(stderr, "prove call %u: B %u inflight %d deep %d behind_sliced %d dual %d rotate %d par %d\n", call, B, inflight, (int)deep, (int)behind_sliced, (int)dual, (int)rotate, par);
     if (rotate) {
         const int hs = 1 + (int)(call % (u32)(bbp_ctx::MAX_SLICES - 1));
         hipStream_t ls = ctx->lane[hs];
@@ -1507,6 +1535,10 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
     BBP_HIP_TRY(ctx, hipEventRecord(ctx->ev_done[par], main_s));
     ctx->ev_done_valid[par] = true;
     ctx->last_par = par;
+    ctx->last_sliced = !rotate;
+    ctx->last_prove_par = par;
+    BBP_HIP_TRY(ctx, hipEventRecord(ctx->ev_call[call % (u32)bbp_ctx::CALL_RING], main_s));
+    ctx->ev_call_valid[call % (u32)bbp_ctx::CALL_RING] = true;
     return BBP_OK;  // ~StreamGuard records ev_last on the caller's stream
 }
 

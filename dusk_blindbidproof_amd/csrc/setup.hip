@@ -192,6 +192,9 @@ static int32_t init_body(int32_t device, bbp_ctx** out) {
     if (const char* e = getenv("BBP_VERIFY_AGGREGATE")) ctx->verify_group = atoi(e) > 1 ? (uint32_t)atoi(e) : 0u;
     if (const char* e = getenv("BBP_DUAL_OPEN_BELOW")) ctx->dual_open_below = atoi(e);
     if (const char* e = getenv("BBP_ROTATE_BELOW")) ctx->rotate_below = atoi(e);
+    if (const char* e = getenv("BBP_ROTATE_MIXED_FROM")) ctx->mixed_from = atoi(e);
+    if (const char* e = getenv("BBP_ROTATE_DEEP_MAX")) ctx->rotate_deep_max = atoi(e);
+    if (const char* e = getenv("BBP_ROTATE_DEEP_FROM")) ctx->deep_from = atoi(e) < 2 ? 2 : atoi(e);
     if (const char* e = getenv("BBP_VARBASE_LANES")) ctx->varbase_lanes = atoi(e) < 64 ? 64 : atoi(e);
     if (const char* e = getenv("BBP_TAIL_ROUND")) ctx->tail_round = atoi(e) == bbp::FOLD_ROUND ? bbp::FOLD_ROUND : 12;
     if (const char* e = getenv("BBP_STAGGER")) ctx->stagger_mode = atoi(e);
@@ -213,6 +216,7 @@ static int32_t init_body(int32_t device, bbp_ctx** out) {
         BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_open[i], hipEventDisableTiming));
         BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_done[i], hipEventDisableTiming));
     }
+    for (auto& e : ctx->ev_call) BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
 
     // --- host hashing -----------------------------------------------------------------------------
     const size_t n_uniform = 2 * BBP_GENS_CAPACITY + 1;
@@ -321,6 +325,8 @@ extern "C" void bbp_free(bbp_ctx* ctx) {
         if (ctx->ev_open[i]) (void)hipEventDestroy(ctx->ev_open[i]);
         if (ctx->ev_done[i]) (void)hipEventDestroy(ctx->ev_done[i]);
     }
+    for (auto& e : ctx->ev_call)
+        if (e) (void)hipEventDestroy(e);
     for (int i = 1; i < bbp_ctx::MAX_SLICES; i++) {
         if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
         if (ctx->ev_stagger[i - 1]) (void)hipEventDestroy(ctx->ev_stagger[i - 1]);
