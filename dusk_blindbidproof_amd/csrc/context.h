@@ -90,6 +90,7 @@ struct bbp_ctx {
     int rotate_deep_max = 4096;            // calls of up to this many proofs issued while two or more earlier prove calls are still in flight take the rotating path too (BBP_ROTATE_DEEP_MAX, 0 = never; never with BBP_SLICES=1)
     bool deep_mode = false, force_deep = false;  // (state of that rule; force_deep: bbp_reserve warming the rotating path's buffers)
     int deep_idle_seen = 0;
+    bool trace_prove = false;              // BBP_TRACE_PROVE: one stderr line per prove call with the schedule it took
     static constexpr int CALL_RING = 8;
     hipEvent_t ev_call[CALL_RING] = {};    // completion of the last CALL_RING prove calls (how many are still in flight)
     bool ev_call_valid[CALL_RING] = {};

@@ -1506,8 +1506,7 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
     // one of the three internal slice streams in rotation (own scratch slot each, like slices): up to three calls' chains in
     // flight; the caller's stream only waits for the result.
     const bool rotate = dual && ((ctx->rotate_below > 0 && B <= (u32)ctx->rotate_below) || (deep && B > (u32)ctx->rotate_below));
-    static const bool trace_calls = getenv("BBP_TRACE_PROVE") != nullptr;
-    if (trace_calls) fprintf(stderr, "prove call %u: B %u inflight %d deep %d behind_sliced %d dual %d rotate %d par %d\n", call, B, inflight, (int)deep, (int)behind_sliced, (int)dual, (int)rotate, par);
+    if (ctx->trace_prove) fprintf(stderr, "prove call %u: B %u inflight %d deep %d behind_sliced %d dual %d rotate %d par %d\n", call, B, inflight, (int)deep, (int)behind_sliced, (int)dual, (int)rotate, par);
     if (rotate) {
         const int hs = 1 + (int)(call % (u32)(bbp_ctx::MAX_SLICES - 1));
         hipStream_t ls = ctx->lane[hs];

@@ -193,6 +193,7 @@ static int32_t init_body(int32_t device, bbp_ctx** out) {
     if (const char* e = getenv("BBP_DUAL_OPEN_BELOW")) ctx->dual_open_below = atoi(e);
     if (const char* e = getenv("BBP_ROTATE_BELOW")) ctx->rotate_below = atoi(e);
     if (const char* e = getenv("BBP_ROTATE_MIXED_FROM")) ctx->mixed_from = atoi(e);
+    ctx->trace_prove = getenv("BBP_TRACE_PROVE") != nullptr;
     if (const char* e = getenv("BBP_ROTATE_DEEP_MAX")) ctx->rotate_deep_max = atoi(e);
     if (const char* e = getenv("BBP_ROTATE_DEEP_FROM")) ctx->deep_from = atoi(e) < 2 ? 2 : atoi(e);
     if (const char* e = getenv("BBP_VARBASE_LANES")) ctx->varbase_lanes = atoi(e) < 64 ? 64 : atoi(e);

@@ -190,7 +190,11 @@ int32_t bbp_verify_batch(bbp_ctx* ctx, uint32_t B, uint32_t N, const uint8_t* in
  * is made: the prover's opening stage (witness, commitments, transcript rng) starts at once on an internal stream so that
  * it overlaps the previous call's MSM stage; outputs are ordered on `stream` as usual: complete for anything enqueued on
  * `stream` after the call, and not written before everything enqueued on `stream` ahead of the call has finished.  entropy_dev: B * bbp_entropy_size(N) for prove,
- * B * 32 for verify (the verifier's TranscriptRng seed).  status_dev: B * int32. */
+ * B * 32 for verify (the verifier's TranscriptRng seed).  status_dev: B * int32.
+ * Scheduling (results never depend on it): a prove call's MSM-heavy stage runs as three slices on three streams; calls below 1024
+ * proofs, and calls of any size up to 4096 made while THREE OR MORE earlier prove calls are still in flight, run it unsliced on one
+ * of three internal streams in rotation instead (whole calls overlap; higher throughput for a caller that queues ahead, at the
+ * price of a longer time to each call's records: BBP_ROTATE_DEEP_FROM / BBP_ROTATE_DEEP_MAX). */
 int32_t bbp_prove_batch_dev(bbp_ctx* ctx, uint32_t B, uint32_t N, const void* in_dev, const void* entropy_dev, void* out_dev,
                             void* stream);
 int32_t bbp_verify_batch_dev(bbp_ctx* ctx, uint32_t B, uint32_t N, const void* in_dev, const void* entropy_dev, void* status_dev,
@@ -213,8 +217,8 @@ int32_t bbp_verify_batch_aggregated_dev(bbp_ctx* ctx, uint32_t B, uint32_t N, co
 /* Optional, once after bbp_init (or whenever a new list length N shows up): grow every per-batch buffer of the context (every member
  * of a pool) to what batches of up to max_batch proofs / verifications of list length N need, and compile the circuit for N.
  * Without it the buffers grow on demand, and a call that finds them too small frees and reallocates gigabytes under load (the
- * whole device waits: ~0.1-1 s, once per new high-water mark).  Costs about three prove batches of that size; ~1.3 MB of device
- * memory per proof and buffer. */
+ * whole device waits: ~0.1-1 s, once per new high-water mark).  Costs about a dozen prove batches of that size (every schedule's buffers:
+ * two for sliced calls, five for calls in rotation, the staging slots of the host-pointer calls); ~1.3 MB of device memory per proof and buffer. */
 int32_t bbp_reserve(bbp_ctx* ctx, uint32_t max_batch, uint32_t N);
 
 /* Micro-batching window of the call combiner, microseconds (default 0: a batch leaves as soon as the engine is free).  With a

@@ -464,6 +464,59 @@ def test_pipelined_calls_of_mixed_batch_sizes(bbp, oc):
         c2.close()
 
 
+def test_deep_pipeline_takes_the_rotating_path_with_the_same_bytes(bbp, oc, capfd):
+    """A caller that keeps three or more prove calls in flight is moved from slices of one call to whole calls in rotation
+    (prover.hip "deep"); a batch that arrives behind a sliced one and is not small takes the sliced path.  Neither changes a byte:
+    every pipelined call must reproduce the records of the same inputs proven alone, and the engine's own trace must show that the
+    rotating path was actually taken."""
+    import os
+    import torch
+    dev = torch.device("cuda", 0)
+    knobs = {"BBP_ROTATE_BELOW": "0", "BBP_DUAL_OPEN_BELOW": "0", "BBP_ROTATE_MIXED_FROM": "64", "BBP_TRACE_PROVE": "1"}  # every batch size counts as large
+    old = {k: os.environ.get(k) for k in knobs}
+    os.environ.update(knobs)
+    try:
+        c2 = bbp.Context(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    try:
+        N = 2
+        rs_ = bbp.record_size(N)
+        sets = []
+        for k, B in enumerate((70, 200, 33)):
+            ins, ents, _ = _synth_batch(c2, B, N, seed=1500 + k)
+            d_in = torch.frombuffer(bytearray(b"".join(ins)), dtype=torch.uint8).to(dev)
+            d_ent = torch.frombuffer(bytearray(b"".join(ents)), dtype=torch.uint8).to(dev)
+            solo, st = c2.prove_batch(B, N, b"".join(ins), b"".join(ents))
+            assert st == [0] * B
+            rc, exp = oc.prove(ins[B - 1][:224], ins[B - 1][224:224 + 32 * N], int.from_bytes(ins[B - 1][-8:], "little"), ents[B - 1])
+            assert rc == 0 and solo[(B - 1) * rs_:] == exp
+            sets.append((B, d_in, d_ent, solo))
+        torch.cuda.synchronize()
+        capfd.readouterr()
+        s = torch.cuda.current_stream().cuda_stream
+        outs = []
+        for it in range(14):
+            B, d_in, d_ent, solo = sets[it % 3]
+            out = torch.zeros(B * rs_, dtype=torch.uint8, device=dev)
+            c2.prove_batch_dev(B, N, d_in.data_ptr(), d_ent.data_ptr(), out.data_ptr(), s)
+            outs.append((out, solo))
+        torch.cuda.synchronize()
+        for it, (out, solo) in enumerate(outs):
+            assert bytes(out.cpu().numpy().tobytes()) == solo, it
+        trace = [l for l in capfd.readouterr().err.splitlines() if l.startswith("prove call")]
+        assert len(trace) == 14
+        assert " rotate 0 " in trace[0] and " deep 0 " in trace[0]          # nothing in flight yet: slices
+        assert sum(" deep 1 " in l and " rotate 1 " in l for l in trace) >= 8  # the pipeline filled up: whole calls in rotation
+        assert c2.health() == 0
+    finally:
+        c2.close()
+
+
 def test_pipelined_calls_with_different_list_lengths(ctx, oc, bbp):
     """Consecutive device calls with different N use different compiled circuits (index lists, constraint tables) while the
     previous call is still in flight: outputs must equal the solo runs and the oracle's record."""
