@@ -671,7 +671,7 @@ class StreamWorkload(_Base):
 
 def make_workload(name, ctx, bbp, torch, device, batch, items, seed):
     if name == "stream":
-        return StreamWorkload(ctx, bbp, torch, device, batch, items, seed)
+        return StreamWorkload(ctx, bbp, torch, device, batch, items, seed, depth=int(os.environ.get("BBP_BENCH_STREAM_DEPTH", "3")))
     if name in ("auto", "prove"):
         return ProveWorkload(ctx, bbp, torch, device, batch, items, seed)
     if name == "msm":
