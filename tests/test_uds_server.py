@@ -221,6 +221,24 @@ def test_combiner_under_thread_sanitizer(built):
     assert "wrong 0, bad batches 0" in p.stdout, p.stdout
 
 
+def test_combiner_waits_out_a_lopsided_pair_of_batches(built):
+    """Closed-loop callers (every reply answered by the next request) that start with a small batch in flight beside a large one:
+    without the lopsided-pair rule that state perpetuates itself -- the small batch's callers come back early and are sent again
+    at once, 100 / 500 for the whole run -- with it the few wait for the large batch's callers and the burst is cut in half: equal
+    batches from then on (csrc/submit.cpp; measured through the UDS server in profiles/r03_uds_lopsided_ab.jsonl)."""
+    import re
+    exe = built.build_combiner_rules()
+    res = {}
+    for rule in (1, 0):
+        p = subprocess.run([exe, str(rule)], capture_output=True, text=True, timeout=120)
+        assert p.returncode == 0, p.stdout + p.stderr[-2000:]
+        m = re.search(r"RESULT min (\d+) max (\d+) wrong 0 live 0", p.stdout)
+        assert m, p.stdout
+        res[rule] = (int(m.group(1)), int(m.group(2)))
+    assert res[1][0] >= 200 and res[1][1] <= 400, res   # 600 callers in two equal batches
+    assert res[0][0] * 2 < res[0][1], res               # (the harness does reproduce the state the rule is for)
+
+
 def test_connections_are_dealt_over_several_device_contexts(built):
     """--devices a,b,..: one engine context per GPU, connections round-robin (independent bids: no cross-GPU traffic on this
     path).  With the stub both contexts are fakes; the plumbing -- two contexts created, both used, statistics summed -- is real."""
