@@ -173,6 +173,10 @@ static int32_t init_body(int32_t device, bbp_ctx** out) {
     // stage keeps busy (stream, side, lane[1], lane[2]) must not share one (measured: with the copy stream created third, a
     // 1024-proof batch took 60.9 instead of 55.6 ms)
     BBP_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking));
+    // the small-batch path's second opening stream, BEFORE the verifier lanes: with 8 hardware queues (what bbp-uds-server exports) the seventh
+    // stream still gets a queue of its own; created lazily, as the eleventh, it shared lane[1]'s, and a 10 ms opening stage sat in the same
+    // queue as a heavy-stage chain (through the socket, 8 000 proofs/s offered: prove p50 / p99 55 / 80 -> 41.5 / 51.5 ms; 16 000: 111 / 149 -> 88 / 108)
+    BBP_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side2, hipStreamNonBlocking));
     for (auto& L : ctx->vl) {
         BBP_HIP_TRY(ctx, hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
         BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&L.ev_vfork, hipEventDisableTiming));
