@@ -87,9 +87,10 @@ struct bbp_ctx {
     hipStream_t side2 = nullptr;           // second opening stream: batches too small to fill three heavy slices alternate between the two
     int varbase_lanes = 65536;             // lanes the verifier's variable-base kernel is launched with (BBP_VARBASE_LANES): ~1 wave per SIMD
     int rotate_below = 1023;               // batches of at most this many proofs run their heavy stage unsliced on a rotating internal stream (BBP_ROTATE_BELOW, 0 = never)
-    int rotate_deep_max = 4096;            // calls of up to this many proofs issued while two or more earlier prove calls are still in flight take the rotating path too (BBP_ROTATE_DEEP_MAX, 0 = never; never with BBP_SLICES=1)
+    int rotate_deep_max = 4096;            // calls of up to this many proofs issued while deep_from or more earlier prove calls are still in flight take the rotating path too (BBP_ROTATE_DEEP_MAX, 0 = never; never with BBP_SLICES=1)
     bool deep_mode = false, force_deep = false;  // (state of that rule; force_deep: bbp_reserve warming the rotating path's buffers)
     int deep_idle_seen = 0;
+    std::vector<hipStream_t> spare_streams;  // (experiment BBP_VL_SKIP: placeholders in the hardware-queue round-robin)
     bool trace_prove = false;              // BBP_TRACE_PROVE: one stderr line per prove call with the schedule it took
     static constexpr int CALL_RING = 8;
     hipEvent_t ev_call[CALL_RING] = {};    // completion of the last CALL_RING prove calls (how many are still in flight)

@@ -178,6 +178,14 @@ static int32_t init_body(int32_t device, bbp_ctx** out) {
     // queue as a heavy-stage chain (through the socket, 8 000 proofs/s offered: prove p50 / p99 55 / 80 -> 41.5 / 51.5 ms; 16 000: 111 / 149 -> 88 / 108)
     BBP_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side2, hipStreamNonBlocking));
     for (auto& L : ctx->vl) {
+#ifdef BBP_VL_SKIP  // experiment: unused streams after the first verifier lane, so that with 8 hardware queues the other lanes skip the queues of the caller's and the opening stream
+        if (&L == &ctx->vl[1])
+            for (int k = 0; k < BBP_VL_SKIP; k++) {
+                hipStream_t d;
+                BBP_HIP_TRY(ctx, hipStreamCreateWithFlags(&d, hipStreamNonBlocking));
+                ctx->spare_streams.push_back(d);
+            }
+#endif
         BBP_HIP_TRY(ctx, hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
         BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&L.ev_vfork, hipEventDisableTiming));
         BBP_HIP_TRY(ctx, hipEventCreateWithFlags(&L.ev_vjoin, hipEventDisableTiming));
@@ -343,6 +351,8 @@ extern "C" void bbp_free(bbp_ctx* ctx) {
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
     if (ctx->copy) (void)hipStreamDestroy(ctx->copy);
     if (ctx->side2) (void)hipStreamDestroy(ctx->side2);
+    for (hipStream_t d : ctx->spare_streams) (void)hipStreamDestroy(d);
+    ctx->spare_streams.clear();
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
