@@ -409,7 +409,7 @@ extern "C" int32_t bbp_describe(bbp_ctx* ctx, char* buf, uint32_t cap) {
         // The engine keeps four streams busy during a prove call (caller's, opening stage, two more slices) and four more for
         // verification (one per lane), out of eleven it creates: HIP's default of four hardware queues makes them share and serialise
         // (measured 84.5 vs 61.6 ms per prove batch).  How many are best depends on the mix: 8 for prove-dominated host-pointer use
-        // (the UDS server: 20.4 k proofs/s against 17.1 k with 16), 16 for verification on all four lanes through the device API
+        // (the UDS server: the seven prover streams are created first and have a queue each; a few percent better than 16 at saturation), 16 for verification on all four lanes through the device API
         // (1024 per call: 5.2 ms against 7.2 with 8): INTEGRATION.md section 5.  The variable is read when the HIP runtime
         // initialises, i.e. possibly long before bbp_init.
         if ((!hwq || atoi(hwq) < 8) && off + 1 < cap)
