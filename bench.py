@@ -322,7 +322,14 @@ def main():
     alu_peak = None if STUB else max(ctx.ubench(3, 8192, 2000) for _ in range(2))  # register-resident ge_madd chains: the integer-ALU ceiling
     dt, timings = timed(wl, ctx, torch, dist, world, args.steps, stream)
     tmax = torch.tensor([dt], device=red_dev, dtype=torch.float64)
+    per_rank_s = [dt]
     if world > 1:
+        # every rank's own clock beside the max-over-ranks figure: a straggler GPU (clocks, a shared PCIe switch, a noisy neighbour)
+        # is visible in the one SCALE line instead of only dragging `value` down
+        mine = tmax.clone()
+        allt = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allt, mine)
+        per_rank_s = [float(t.item()) for t in allt]
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     # The path's one collective: every rank's proof records / flags to rank 0 in global proof order, after the timed
@@ -386,6 +393,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": wl.data, "config": wl.config,
         }
+        if world > 1:
+            out["per_rank"] = {"value": [wl.units_per_step * args.steps / t for t in per_rank_s], "ms_per_step": [t / args.steps * 1e3 for t in per_rank_s],
+                               "note": "each rank's own units/s over its own clock between the barriers; `value` = all units / the slowest rank's time"}
         if not STUB:
             out["roofline"] = roofline(wl, timings, args.steps, alu_peak, dt)
             if exclusive:

@@ -202,8 +202,8 @@ extern "C" int32_t bbp_prepare_bids_dev(bbp_ctx* ctx, uint32_t B, uint32_t N, co
         hipStream_t s = pick_stream(ctx, stream);
         // one lane per bid, 4 x 90 sequential MiMC rounds: a serial wave that lives for milliseconds.  In a pipeline it runs beside
         // another chunk's MSM stage, so it is fenced onto CUs of its own like the prover's opening kernels
-        if ((rc = serial_lds_bytes(ctx, (const void*)k_prepare_bids))) return rc;
-        const unsigned hog = ctx->serial_lds > 0 ? (unsigned)ctx->serial_lds : 0u;
+        unsigned hog = 0;  // what the launch may ask for: the reservation minus the kernel's own static LDS (serial_lds_bytes sets the attribute to exactly this)
+        if ((rc = serial_lds_bytes(ctx, (const void*)k_prepare_bids, &hog))) return rc;
         {
             ScopedEvent ev(ctx, TAG_WITNESS, s);
             hipLaunchKernelGGL(k_prepare_bids, dim3((B + 63) / 64), dim3(64), hog, s, B, N, (const u8*)bids_dev, (const u8*)lists_dev,
@@ -760,8 +760,11 @@ extern "C" int32_t bbp_reserve(bbp_ctx* ctx, uint32_t max_batch, uint32_t N) {
         int32_t rc = BBP_OK;
         // batches below 1024 proofs rotate three buffers and two opening streams, larger ones two buffers: both shapes, every slot
         for (int k = 0; k < bbp_ctx::IO_SLOTS && rc == BBP_OK; k++) rc = prove_batch_host(ctx, B, N, in.data(), ent.data(), out.data(), st.data());
+        // the small-batch path rotates over ALL five batch buffers (buffer = call % PROVE_BUFS): five more calls whatever B is -- with
+        // max_batch < 1024 the loop above IS that path but touches only three of them, and the first 4th / 5th call under load would
+        // grow its buffer with hipFree + hipMalloc: the stall this function exists to prevent
         const uint32_t small = B < 1023 ? B : 1023;
-        for (int k = 0; k < bbp_ctx::PROVE_BUFS && rc == BBP_OK && B >= 1024; k++) rc = prove_batch_host(ctx, small, N, in.data(), ent.data(), out.data(), st.data());
+        for (int k = 0; k < bbp_ctx::PROVE_BUFS && rc == BBP_OK; k++) rc = prove_batch_host(ctx, small, N, in.data(), ent.data(), out.data(), st.data());
         // ... and the shape a caller with several calls in flight gets (prover.hip "deep"): whole calls of B in rotation, five buffers
         if (B >= 1024 && ctx->slices > 1 && ctx->rotate_deep_max > 0 && B <= (uint32_t)ctx->rotate_deep_max) {
             struct Reset { bool& b; ~Reset() { b = false; } } reset{ctx->force_deep};

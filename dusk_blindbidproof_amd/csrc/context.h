@@ -2,6 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include <condition_variable>
 #include <map>
@@ -78,6 +81,7 @@ struct bbp_ctx {
     // handle the reference's prove() / verify() callers share when the node has several GPUs: ONE combiner deals their batches to
     // the members (one ordinary context per GPU), the host-pointer batch calls block-split over them.  A member knows its pool.
     std::vector<bbp_ctx*> members;
+    void* pool_workers = nullptr;  // bbp::PoolWorkers* (pool.cpp): the members' persistent host threads for the block-split batch calls
     bbp_ctx* owner = nullptr;
     uint32_t member_index = 0;
     int device = 0;
@@ -214,6 +218,8 @@ struct bbp_ctx {
     std::map<uint32_t, void*> circuits;  // N -> CircuitDev* (compiled blind-bid circuit tables on the device)
     std::map<uint64_t, bbp::u32*> layout_idx;  // (layout << 32 | n_terms) -> device base-index list of bbp_msm_batch (capi_msm.hip)
     std::vector<float> timings;
+    uint64_t scratch_allocs = 0;  // dev_reserve: how many times a grow-only scratch buffer was (re)allocated since bbp_init ...
+    size_t scratch_bytes = 0;     // ... and what they hold now (bbp_describe)
     // optional per-kernel HIP-event timing (bbp_set_profiling): (tag, start, stop) on the launch stream
     bool profile = false;
     struct Ev {
@@ -225,8 +231,30 @@ struct bbp_ctx {
 
 namespace bbp {
 
+// BBP_DEBUG_DEVICE_CHECK=1 (on in every -m gpu test): before EVERY HIP call the engine makes on behalf of a context -- launches
+// (their hipGetLastError), event records / waits, allocations, copies -- the calling thread's current device must be the context's.
+// A process with one context per GPU (the pool, bbp-uds-server --devices, one combiner thread hopping between members) depends on
+// every entry point, every combiner batch thread and every pool worker having called hipSetDevice first; on a one-GPU box a missing
+// call is invisible, on the first 8-GPU node it is a stream / event of device A used with device B current.  With the check on such a
+// call fails with BBP_ERR_DEVICE and names the call site instead.  (hipSetDevice itself is exempt: it is the call that establishes
+// the state.)  Cost when on: one thread-local read per HIP call; when off: one predictable branch.
+inline bool device_check_on() {
+    static const bool on = [] { const char* e = getenv("BBP_DEBUG_DEVICE_CHECK"); return e && atoi(e) != 0; }();
+    return on;
+}
+inline bool device_affinity_ok(bbp_ctx* ctx, const char* what) {
+    if (!device_check_on() || ctx->device < 0) return true;
+    if (!strncmp(what, "hipSetDevice", 12) || !strncmp(what, "hipGetDeviceCount", 17)) return true;
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur == ctx->device) return true;
+    ctx->err = "device affinity violated: current device " + std::to_string(cur) + ", context lives on device " + std::to_string(ctx->device) + ", at " + what;
+    fprintf(stderr, "[bbp] %s\n", ctx->err.c_str());
+    return false;
+}
+
 #define BBP_HIP_TRY(ctx, expr)                                                                         \
     do {                                                                                               \
+        if (!bbp::device_affinity_ok(ctx, #expr)) return BBP_ERR_DEVICE;                               \
         hipError_t _e = (expr);                                                                        \
         if (_e != hipSuccess) {                                                                        \
             (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                            \
@@ -236,12 +264,17 @@ namespace bbp {
 
 inline int32_t dev_reserve(bbp_ctx* ctx, DevBuf& b, size_t bytes) {
     if (b.cap >= bytes) return BBP_OK;
-    if (b.p) BBP_HIP_TRY(ctx, hipFree(b.p));
+    if (b.p) {
+        BBP_HIP_TRY(ctx, hipFree(b.p));
+        ctx->scratch_bytes -= b.cap;
+    }
     b.p = nullptr;
     b.cap = 0;
     size_t want = bytes + (bytes >> 3) + 4096;
     BBP_HIP_TRY(ctx, hipMalloc(&b.p, want));
     b.cap = want;
+    ctx->scratch_bytes += want;
+    ctx->scratch_allocs++;  // bbp_describe reports both: after bbp_reserve the count must stand still (tests/test_gpu_boundary.py)
     return BBP_OK;
 }
 
@@ -368,11 +401,18 @@ int32_t api_guard(bbp_ctx* ctx, F&& body) noexcept {
 }
 
 inline bool is_pool(const bbp_ctx* ctx) { return ctx && !ctx->members.empty(); }
+// setup.hip: GPU_MAX_HW_QUEUES is exported by the library itself when the process has not initialised HIP yet (state: 1 the caller's
+// environment had it, 2 set here, 3 too late)
+void own_hw_queues();
+int hw_queues_state();
 // pool.cpp: the host-pointer batch calls on a pool handle (block split by index over the members, results in request order)
 int32_t pool_prove_batch(bbp_ctx* pool, uint32_t B, uint32_t N, const uint8_t* in, const uint8_t* entropy, uint8_t* out, int32_t* status);
 int32_t pool_verify_batch(bbp_ctx* pool, uint32_t B, uint32_t N, const uint8_t* in, int32_t* status, bool aggregated, uint32_t group, uint32_t* n_fallback);
 int32_t pool_msm_batch(bbp_ctx* pool, uint32_t B, uint32_t n_terms, const uint8_t* scalars, uint32_t layout, uint8_t* out32);
 int32_t pool_reject(bbp_ctx* pool, const char* what);  // BBP_ERR_BAD_ARG + message: entry points that need ONE device
+void pool_workers_start(bbp_ctx* pool);
+void pool_workers_stop(bbp_ctx* pool);
+int pool_member_numa_node(const bbp_ctx* pool, uint32_t i);
 
 // msm.hip
 // base_idx_dev holds n_idx_sets lists of n_terms indices; MSM number i uses list (i % n_idx_sets)

@@ -98,6 +98,54 @@ __device__ __forceinline__ row_regs load_row(const niels_row* __restrict__ tab, 
     return load_row_at(tab + row, entry >> 31);
 }
 
+// -DBBP_ACC_COOP: wave-cooperative row fetch (round 4).  The plain path has every lane pull its own 128-byte row in ten pieces of
+// 8-16 bytes: each of those wave-instructions touches 64 different cache lines (MI355X_MICROARCH.md, access shape: the slowest
+// one).  Here eight consecutive lanes fetch ONE row's 8 x 16 bytes, so a wave-instruction covers 8 whole lines, eight instructions
+// a wave's 64 rows -- straight into a per-wave LDS image by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write), one
+// iteration ahead; a lane then reads its own row with ds_read_b128 / b64.  No workgroup barrier: the image belongs to the wave.
+//   image: slot L (128 bytes) = row of lane L; logical 16-byte piece s sits at position s ^ ((L >> 1) & 7), so that the sixteen
+//   lanes an LDS b128 read serves together hit sixteen different bank groups (the swizzle is applied on the SOURCE address: an
+//   LDS-DMA writes wave-uniform base + lane * 16).
+#ifdef BBP_ACC_COOP
+constexpr int COOP_IMG = 64 * 128;  // bytes per wavefront
+__device__ __forceinline__ u32 coop_clamp_row(u32 entry, u32* __restrict__ fault) {
+    u32 row = entry & 0x7fffffffu;
+    if (row > (u32)(TAB_BASES * MSM_POS - 1)) {
+        row = (u32)(TAB_BASES * MSM_POS - 1);
+        atomicOr(fault, 1u);
+    }
+    return row;
+}
+// all 64 lanes, EXEC full: lane l fetches piece (l & 7) ^ k of the row that lane 8 j + (l >> 3) will add next
+__device__ __forceinline__ void coop_issue(const niels_row* __restrict__ tab, u8* wb, u32 my_row, int lane, u32 srcoff) {
+    const u8* t = reinterpret_cast<const u8*>(tab);
+    u32 r[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) r[j] = (u32)__shfl((int)my_row, 8 * j + (lane >> 3), 64);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const u8* src = t + (size_t)r[j] * 128 + (srcoff ^ (u32)((j & 1) << 6));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(wb + j * 1024), 16, 0, 0);
+    }
+}
+// this lane's row out of the image; a negative digit swaps y+x and y-x (pieces s and s ^ 4), 2dxy stays where it is
+__device__ __forceinline__ row_regs coop_read(const u8* wb, u32 A, u32 neg) {
+    const u32 An = A ^ (neg << 6);
+    const uint4 a0 = *reinterpret_cast<const uint4*>(wb + An), a1 = *reinterpret_cast<const uint4*>(wb + (An ^ 0x10u));
+    const uint2 a2 = *reinterpret_cast<const uint2*>(wb + (An ^ 0x20u));
+    const uint4 b0 = *reinterpret_cast<const uint4*>(wb + (An ^ 0x40u)), b1 = *reinterpret_cast<const uint4*>(wb + (An ^ 0x50u));
+    const uint2 b2 = *reinterpret_cast<const uint2*>(wb + (An ^ 0x60u));
+    const uint2 x0 = *reinterpret_cast<const uint2*>(wb + (A ^ 0x20u) + 8);
+    const uint4 x1 = *reinterpret_cast<const uint4*>(wb + (A ^ 0x30u));
+    const uint2 x2 = *reinterpret_cast<const uint2*>(wb + (A ^ 0x60u) + 8), x3 = *reinterpret_cast<const uint2*>(wb + (A ^ 0x70u));
+    row_regs r;
+    r.ypx = fe{{(i32)a0.x, (i32)a0.y, (i32)a0.z, (i32)a0.w, (i32)a1.x, (i32)a1.y, (i32)a1.z, (i32)a1.w, (i32)a2.x, (i32)a2.y}};
+    r.ymx = fe{{(i32)b0.x, (i32)b0.y, (i32)b0.z, (i32)b0.w, (i32)b1.x, (i32)b1.y, (i32)b1.z, (i32)b1.w, (i32)b2.x, (i32)b2.y}};
+    r.xy2d = fe{{(i32)x0.x, (i32)x0.y, (i32)x1.x, (i32)x1.y, (i32)x1.z, (i32)x1.w, (i32)x2.x, (i32)x2.y, (i32)x3.x, (i32)x3.y}};
+    return r;
+}
+#endif
+
 // The cold phases (bucket fold, cross-lane reduction) call ONE out-of-line copy of the point addition / doubling: inlining
 // them at every site made the kernel 124 KB, and with workgroups of a CU in different phases the 64 KB instruction cache
 // thrashed under the hot mixed-addition loop (measured: that loop ran 1.7x slower than the same code in isolation).
@@ -399,6 +447,55 @@ void k_msm_acc(const niels_row* __restrict__ ptable, const u32* __restrict__ sor
 #endif
     u32 k_first = 0;         // bucket holding this lane's first entry
     bool inside = false;     // the chunk starts strictly inside it: its leading partial sum went to psum[tid]
+#ifdef BBP_ACC_COOP
+    {
+        // Same walk, but the trip count is uniform over the workgroup (chunks differ by at most one entry: n_it = ceil(E / ACC_T);
+        // a lane whose chunk is through idles in the last trip) because every lane takes part in every cooperative fetch.
+        __shared__ __attribute__((aligned(1024))) u8 rowimg[ACC_WG / 64][COOP_IMG];
+        const int lane = (int)threadIdx.x & 63;
+        u8* wb = rowimg[threadIdx.x >> 6];
+        const u32 A = (u32)lane * 128u + ((((u32)lane >> 1) & 7u) << 4);            // reader: slot | swizzle
+        const u32 srcoff = (((u32)lane & 7u) ^ (((u32)lane >> 3) >> 1)) << 4;        // loader: piece of the row this lane fetches (j even)
+        const u32 n_it = (E + (u32)ACC_T - 1) / (u32)ACC_T, len = c1 - c0;
+        u32 k = 1, kend = 0;
+        ge* dest = &psum[tid];
+        if (len) {
+            u32 lo = 1, hi = K;  // bucket containing entry c0: smallest k with cursor[k] > c0
+            while (lo < hi) {
+                u32 mid = (lo + hi) >> 1;
+                if (cursor[mid] > c0) hi = mid; else lo = mid + 1;
+            }
+            k = lo, kend = cursor[k];
+            k_first = lo;
+            inside = cursor[k - 1] < c0;
+            if (!inside) dest = &bsum[k - 1];
+        }
+        ge acc = ge_identity();
+        u32 ent_cur = len ? sorted[c0] : 0u;
+        u32 ent_nxt = len > 1 ? sorted[c0 + 1] : 0u;
+        if (n_it) coop_issue(ptable, wb, coop_clamp_row(ent_cur, fault), lane, srcoff);
+        for (u32 it = 0; it < n_it; it++) {
+            const u32 e = c0 + it;
+            const row_regs cur = coop_read(wb, A, ent_cur >> 31);  // (the compiler waits for the LDS-DMA of the previous trip here)
+            const bool neg = ent_cur >> 31;
+            ent_cur = ent_nxt;
+            const bool live = it < len;
+            if (live && e == kend) {  // crossed into the next non-empty bucket
+                *dest = acc;
+                acc = ge_identity();
+                do { k++; kend = cursor[k]; } while (kend == e);
+                dest = &bsum[k - 1];
+            }
+            // the image is overwritten by the next trip's rows: this trip's reads must have RETURNED first (an LDS-DMA write is
+            // not ordered behind an earlier ds_read by anything but the wave's own wait)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (it + 1 < n_it) coop_issue(ptable, wb, coop_clamp_row(ent_cur, fault), lane, srcoff);
+            if (it + 2 < len) ent_nxt = sorted[e + 2]; else ent_nxt = 0u;
+            if (live) acc = ge_madd_row(acc, cur, neg);
+        }
+        if (len) *dest = acc;
+    }
+#else
     if (c0 < c1) {
         // bucket containing entry c0: smallest k with cursor[k] > c0
         u32 lo = 1, hi = K;
@@ -432,6 +529,7 @@ void k_msm_acc(const niels_row* __restrict__ ptable, const u32* __restrict__ sor
         }
         *dest = acc;
     }
+#endif
 #ifdef BBP_MSM_PROF
     if (tid == 0) atomicAdd(&g_msm_prof[6], clock64() - clk0);
 #endif

@@ -15,6 +15,13 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <sched.h>
+
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -23,6 +30,130 @@
 #include "submit.h"
 
 namespace bbp {
+
+// ---- persistent worker threads, a few per member (round 4) -----------------------------------------------------------------------
+// The host-pointer batch calls on a pool used to start one std::thread per member per call.  Now every member has POOL_WORKERS
+// threads of its own, started at bbp_pool_init: each binds to the member's GPU once (hipSetDevice) and, where sysfs names the NUMA
+// node of that GPU's PCIe root, restricts itself to that node's cores (the staging copies go through pinned host buffers the
+// thread touches: first touch and memcpy stay on the GPU's socket).  Several per member, not one: bbp_prove_batch on a context
+// holds the context lock only while it enqueues and then waits for its staging slot with the lock released -- two or three calls
+// in flight per GPU are what keeps the engine's cross-call pipeline full (one caller thread: 11.0 k proofs/s, two: 18.5 k) -- so
+// concurrent callers of the pool must not serialise on a single worker per member.
+struct PoolWorkers {
+    struct Member {
+        std::mutex mu;
+        std::condition_variable cv;
+        std::deque<std::function<void()>> q;
+        std::vector<std::thread> th;
+        bool stop = false;
+        int numa_node = -1;
+    };
+    std::vector<std::unique_ptr<Member>> m;
+    ~PoolWorkers() {
+        for (auto& mem : m) {
+            {
+                std::lock_guard<std::mutex> lk(mem->mu);
+                mem->stop = true;
+            }
+            mem->cv.notify_all();
+        }
+        for (auto& mem : m)
+            for (auto& t : mem->th)
+                if (t.joinable()) t.join();
+    }
+};
+
+// NUMA node of a GPU from sysfs (-1: unknown / single node); the cores of a node as a cpu_set_t
+static int gpu_numa_node(int device) {
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device) != hipSuccess) return -1;
+    for (char* c = bdf; *c; c++)
+        if (*c >= 'A' && *c <= 'Z') *c = (char)(*c - 'A' + 'a');
+    const std::string path = std::string("/sys/bus/pci/devices/") + bdf + "/numa_node";
+    FILE* f = fopen(path.c_str(), "r");
+    if (!f) return -1;
+    int node = -1;
+    if (fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+    return node;
+}
+static bool numa_node_cpus(int node, cpu_set_t* set) {
+    CPU_ZERO(set);
+    if (node < 0) return false;
+    const std::string path = "/sys/devices/system/node/node" + std::to_string(node) + "/cpulist";
+    FILE* f = fopen(path.c_str(), "r");
+    if (!f) return false;
+    char buf[4096] = {0};
+    const bool got = fgets(buf, sizeof buf, f) != nullptr;
+    fclose(f);
+    if (!got) return false;
+    int n = 0;
+    for (char* p = buf; *p && *p != '\n';) {  // "0-15,128-143"
+        char* end;
+        const long a = strtol(p, &end, 10);
+        if (end == p) break;
+        long b = a;
+        p = end;
+        if (*p == '-') {
+            b = strtol(p + 1, &end, 10);
+            p = end;
+        }
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++) {
+            CPU_SET((int)c, set);
+            n++;
+        }
+        if (*p == ',') p++;
+    }
+    return n > 0;
+}
+
+static void pool_worker_main(PoolWorkers::Member* mem, bbp_ctx* member) {
+    (void)hipSetDevice(member->device);  // once: every task of this thread runs on this member (its entry points set it again)
+    static const bool pin = [] { const char* e = getenv("BBP_POOL_PIN"); return !e || atoi(e) != 0; }();
+    cpu_set_t node_set, allowed;
+    if (pin && numa_node_cpus(mem->numa_node, &node_set) && sched_getaffinity(0, sizeof allowed, &allowed) == 0) {
+        CPU_AND(&node_set, &node_set, &allowed);  // never outside what the container / cpuset allows
+        if (CPU_COUNT(&node_set) > 0) (void)sched_setaffinity(0, sizeof node_set, &node_set);
+    }
+    for (;;) {
+        std::function<void()> job;
+        {
+            std::unique_lock<std::mutex> lk(mem->mu);
+            mem->cv.wait(lk, [&] { return mem->stop || !mem->q.empty(); });
+            if (mem->q.empty()) return;  // stop, and nothing left to run
+            job = std::move(mem->q.front());
+            mem->q.pop_front();
+        }
+        job();
+    }
+}
+
+void pool_workers_start(bbp_ctx* pool) {
+    const char* e = getenv("BBP_POOL_WORKERS");
+    const int per = e && atoi(e) > 0 ? (atoi(e) > 8 ? 8 : atoi(e)) : 3;  // = the staging slots of a context's prove path (IO_SLOTS)
+    auto* w = new PoolWorkers();
+    pool->pool_workers = w;
+    for (bbp_ctx* member : pool->members) {
+        w->m.emplace_back(new PoolWorkers::Member());
+        PoolWorkers::Member* mem = w->m.back().get();
+        mem->numa_node = gpu_numa_node(member->device);
+        for (int k = 0; k < per; k++) {
+            try {
+                mem->th.emplace_back(pool_worker_main, mem, member);
+            } catch (...) {  // fewer threads (or none: for_each_block then runs that member's block on the calling thread)
+                break;
+            }
+        }
+    }
+}
+void pool_workers_stop(bbp_ctx* pool) {
+    delete static_cast<PoolWorkers*>(pool->pool_workers);  // runs what is queued, joins
+    pool->pool_workers = nullptr;
+}
+int pool_member_numa_node(const bbp_ctx* pool, uint32_t i) {
+    const auto* w = static_cast<const PoolWorkers*>(pool->pool_workers);
+    return w && i < w->m.size() ? w->m[i]->numa_node : -1;
+}
 
 int32_t pool_reject(bbp_ctx* pool, const char* what) {
     try {
@@ -41,8 +172,9 @@ static void shard_range(uint32_t B, uint32_t i, uint32_t n, uint32_t* lo, uint32
     *hi = *lo + base + (i < rem ? 1u : 0u);
 }
 
-// run body(member, lo, hi) for every member with a non-empty block, one thread each (the first block on the calling thread);
-// returns the first non-zero status in member order and leaves that member's message in this thread's bbp_last_error slot
+// run body(member, lo, hi) for every member with a non-empty block ON THAT MEMBER'S OWN WORKER THREADS (bound to its GPU, see
+// PoolWorkers; no thread is created per call); the calling thread waits.  Returns the first non-zero status in member order and
+// leaves that member's message in this thread's bbp_last_error slot
 template <class F>
 static int32_t for_each_block(bbp_ctx* pool, uint32_t B, F&& body) {
     const uint32_t n = (uint32_t)pool->members.size();
@@ -54,29 +186,51 @@ static int32_t for_each_block(bbp_ctx* pool, uint32_t B, F&& body) {
         if (lo == hi) return;
         try {
             rc[i] = body(pool->members[i], lo, hi);
-            if (rc[i] != BBP_OK) msg[i] = bbp_last_error(pool->members[i]);  // this worker thread's slot
+            if (rc[i] != BBP_OK) msg[i] = bbp_last_error(pool->members[i]);  // the worker thread's slot
         } catch (...) {
             rc[i] = BBP_ERR_INTERNAL;
             msg[i] = "internal error in a pool worker";
         }
     };
-    std::vector<uint32_t> active, inline_blocks;
+    std::mutex done_mu;
+    std::condition_variable done_cv;
+    uint32_t pending = 0;
+    auto* w = static_cast<PoolWorkers*>(pool->pool_workers);
+    std::vector<uint32_t> inline_blocks;
     for (uint32_t i = 0; i < n; i++) {
         uint32_t lo, hi;
         shard_range(B, i, n, &lo, &hi);
-        if (lo != hi) active.push_back(i);
-    }
-    std::vector<std::thread> th;
-    for (size_t k = 1; k < active.size(); k++) {
-        try {
-            th.emplace_back(run, active[k]);
-        } catch (...) {  // no thread to be had: that block runs on the calling thread after its own
-            inline_blocks.push_back(active[k]);
+        if (lo == hi) continue;
+        bool posted = false;
+        if (w && i < w->m.size() && !w->m[i]->th.empty()) {
+            try {
+                {
+                    std::lock_guard<std::mutex> lk(done_mu);
+                    pending++;
+                }
+                {
+                    std::lock_guard<std::mutex> lk(w->m[i]->mu);
+                    w->m[i]->q.emplace_back([&, i] {
+                        run(i);
+                        std::lock_guard<std::mutex> lk2(done_mu);  // (notify under the lock: the waiter's frame outlives this job)
+                        pending--;
+                        done_cv.notify_one();
+                    });
+                }
+                w->m[i]->cv.notify_one();
+                posted = true;
+            } catch (...) {  // the queue could not take it
+                std::lock_guard<std::mutex> lk(done_mu);
+                pending--;
+            }
         }
+        if (!posted) inline_blocks.push_back(i);
     }
-    if (!active.empty()) run(active[0]);
-    for (uint32_t i : inline_blocks) run(i);
-    for (auto& t : th) t.join();
+    for (uint32_t i : inline_blocks) run(i);  // (a member without workers: on the calling thread; the member's entry points set the device)
+    {
+        std::unique_lock<std::mutex> lk(done_mu);
+        done_cv.wait(lk, [&] { return pending == 0; });
+    }
     for (uint32_t i = 0; i < n; i++)
         if (rc[i] != BBP_OK) {
             try {
@@ -126,6 +280,7 @@ extern "C" int32_t bbp_pool_init(const int32_t* devices, uint32_t n_devices, bbp
     if (!out) return BBP_ERR_BAD_ARG;
     *out = nullptr;
     if (!devices || n_devices == 0 || n_devices > 64) return BBP_ERR_BAD_ARG;
+    own_hw_queues();  // before the first HIP call (setup.hip)
     bbp_ctx* pool = nullptr;
     try {
         pool = new bbp_ctx();
@@ -166,6 +321,7 @@ extern "C" int32_t bbp_pool_init(const int32_t* devices, uint32_t n_devices, bbp
             made[i]->member_index = i;
         }
         pool->members = made;
+        pool_workers_start(pool);
         Combiner* c = new Combiner();
         pool->combiner = c;
         c->set_targets(made);
@@ -196,6 +352,7 @@ extern "C" int32_t bbp_pool_init(const int32_t* devices, uint32_t n_devices, bbp
 extern "C" int32_t bbp_init_all(bbp_ctx** out) {
     if (!out) return BBP_ERR_BAD_ARG;
     *out = nullptr;
+    own_hw_queues();
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
         fprintf(stderr, "bbp_init_all: no usable HIP device (count=%d); this library has no CPU path\n", n);

@@ -1456,9 +1456,11 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
             ctx->ev_prep_valid = false;
         }
         LAUNCH(ctx, TAG_WITNESS, k_fill_mimc, cdiv(B * BBP_MIMC_ROUNDS, 64), 64, s, B, c.n_cst, ctx->mimc_c, bd.cst);
-        if ((rc = serial_lds_bytes(ctx, (const void*)k_open_serial))) return rc;
-        const u32 hog = ctx->serial_lds > 0 ? (u32)ctx->serial_lds : 0u;
-        const u32 sblk = hog ? (u32)ctx->serial_block : 64u;
+        // every launch asks for what serial_lds_bytes set the kernel's limit to (reservation minus the kernel's static LDS): the two
+        // cannot diverge when a kernel gains a __shared__ array
+        u32 hog = 0;
+        if ((rc = serial_lds_bytes(ctx, (const void*)k_open_serial, &hog))) return rc;
+        const u32 sblk = ctx->serial_lds > 0 ? (u32)ctx->serial_block : 64u;
         LAUNCH(ctx, TAG_WITNESS, k_witness_head, cdiv(B, 64), 64, s, B, N, c.n_cst, in_dev, bd.cst, bd.v);
         LAUNCH(ctx, TAG_TRANSCRIPT, k_load_blindings, cdiv(B * m, 64), 64, s, B, m, ent_dev, bd.vb);
         if ((rc = commit_launch(ctx, B * m, bd.v, bd.vb, m, m, m, bd.pts, m + 8, s))) return rc;
@@ -1479,14 +1481,16 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
             const u32 cblk = ctx->rng_block > 0 ? (u32)ctx->rng_block : (B <= 128 ? 64u : B <= 256 ? 128u : 256u);
             if (ctx->rng_dpp) {
                 // one proof per wavefront (k_open_bulk8): the same number of proofs per reserved CU needs twice the lanes
-                if ((rc = serial_lds_bytes(ctx, (const void*)k_open_bulk8))) return rc;
+                u32 hog8 = 0;
+                if ((rc = serial_lds_bytes(ctx, (const void*)k_open_bulk8, &hog8))) return rc;
                 const u32 cblk8 = 2 * cblk > 1024u ? 1024u : 2 * cblk, nb_rng = cdiv(B * 64, cblk8), nb_wit = cdiv(B, cblk8);
-                LAUNCH_LDS(ctx, TAG_RNG, k_open_bulk8, nb_rng + nb_wit, cblk8, hog, s, B, nb_rng, n1, 2 + 2 * n1, bd.rng, (u32*)ctx->raw[sidx].p, m,
+                LAUNCH_LDS(ctx, TAG_RNG, k_open_bulk8, nb_rng + nb_wit, cblk8, hog8, s, B, nb_rng, n1, 2 + 2 * n1, bd.rng, (u32*)ctx->raw[sidx].p, m,
                            c.n_cst, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v, bd.ai1, bd.ao1);
             } else {
-                if ((rc = serial_lds_bytes(ctx, (const void*)k_open_bulk))) return rc;
+                u32 hogb = 0;
+                if ((rc = serial_lds_bytes(ctx, (const void*)k_open_bulk, &hogb))) return rc;
                 const u32 nb_rng = cdiv(B * 32, cblk), nb_wit = cdiv(B, cblk);
-                LAUNCH_LDS(ctx, TAG_RNG, k_open_bulk, nb_rng + nb_wit, cblk, hog, s, B, nb_rng, n1, 2 + 2 * n1, bd.rng, (u32*)ctx->raw[sidx].p, m,
+                LAUNCH_LDS(ctx, TAG_RNG, k_open_bulk, nb_rng + nb_wit, cblk, hogb, s, B, nb_rng, n1, 2 + 2 * n1, bd.rng, (u32*)ctx->raw[sidx].p, m,
                            c.n_cst, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v, bd.ai1, bd.ao1);
             }
         }

@@ -8,6 +8,12 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <dirent.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <mutex>
+
 #include "context.h"
 #include "batch.h"
 #include "hosthash.h"
@@ -100,6 +106,52 @@ static void mimc_constants_host(std::vector<uint8_t>& out) {
 
 }  // namespace bbp
 
+namespace bbp {
+// ---- the library owns its hardware-queue configuration (round 4) ------------------------------------------------------------------
+// A context keeps up to eleven streams (prover: caller's, two opening, three slices, copy; verifier: four lanes); HIP hands hardware
+// queues out in stream-creation order and lets later streams SHARE once GPU_MAX_HW_QUEUES (default 4) are taken -- two busy streams on
+// one queue serialise (prover up to 30 % slower at 4, a verifier lane on a shared queue costs 1024 verifications 7.2 instead of 5.2 ms).
+// The variable is read ONCE, when the HIP runtime initialises in the process.  A host program bound per INTEGRATION.md (Rust, Go, C)
+// would have to know; so bbp_init / bbp_init_all / bbp_pool_init look BEFORE their first HIP call: if the caller's environment has
+// the variable it is left alone; else if HIP / HSA is not up yet in this process (no descriptor on /dev/kfd) the library exports
+// BBP_HWQ_DEFAULT itself; else it is too late, and bbp_describe says so in a WARNING line.
+#ifndef BBP_HWQ_DEFAULT
+#define BBP_HWQ_DEFAULT "16"
+#endif
+static std::atomic<int> g_hwq_state{0};  // 1 caller's environment, 2 set by the library, 3 too late (HIP already initialised, variable unset)
+static bool hsa_is_up() {
+    DIR* d = opendir("/proc/self/fd");
+    if (!d) return false;
+    bool up = false;
+    char path[64], target[256];
+    while (dirent* e = readdir(d)) {
+        if (e->d_name[0] == '.') continue;
+        snprintf(path, sizeof path, "/proc/self/fd/%s", e->d_name);
+        const ssize_t n = readlink(path, target, sizeof target - 1);
+        if (n <= 0) continue;
+        target[n] = 0;
+        if (!strcmp(target, "/dev/kfd")) {
+            up = true;
+            break;
+        }
+    }
+    closedir(d);
+    return up;
+}
+void own_hw_queues() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        if (getenv("GPU_MAX_HW_QUEUES")) g_hwq_state = 1;
+        else if (hsa_is_up()) g_hwq_state = 3;
+        else {
+            setenv("GPU_MAX_HW_QUEUES", BBP_HWQ_DEFAULT, 0);
+            g_hwq_state = 2;
+        }
+    });
+}
+int hw_queues_state() { return g_hwq_state.load(); }
+}  // namespace bbp
+
 using namespace bbp;
 
 static int32_t init_body(int32_t device, bbp_ctx** out);
@@ -107,6 +159,7 @@ static int32_t init_body(int32_t device, bbp_ctx** out);
 extern "C" int32_t bbp_init(int32_t device, bbp_ctx** out) {
     if (!out) return BBP_ERR_BAD_ARG;
     *out = nullptr;
+    own_hw_queues();  // before the first HIP call of this function (and, if possible, of the process)
     if (device == -1) return bbp_init_all(out);  // a pool over every visible GPU (pool.cpp)
     try {
         const int32_t rc = init_body(device, out);
@@ -277,6 +330,7 @@ extern "C" void bbp_free(bbp_ctx* ctx) {
     if (is_pool(ctx)) {  // a pool owns its members and its combiner, no device state
         delete static_cast<Combiner*>(ctx->combiner);  // FIRST: its threads run what is still queued on the members, then leave
         ctx->combiner = nullptr;
+        pool_workers_stop(ctx);  // ... then the members' worker threads (they finish the blocks they hold)
         for (bbp_ctx* m : ctx->members) bbp_free(m);
         ctx->members.clear();
         delete ctx;
@@ -386,7 +440,7 @@ extern "C" int32_t bbp_describe(bbp_ctx* ctx, char* buf, uint32_t cap) {
     if (is_pool(ctx)) {
         uint32_t off = (uint32_t)snprintf(buf, cap, "device pool of %zu member context(s)\n", ctx->members.size());
         for (size_t i = 0; i < ctx->members.size() && off + 1 < cap; i++) {
-            off += (uint32_t)snprintf(buf + off, cap - off, "member %zu: ", i);
+            off += (uint32_t)snprintf(buf + off, cap - off, "member %zu (worker threads on NUMA node %d): ", i, pool_member_numa_node(ctx, (uint32_t)i));
             if (off + 1 >= cap) break;
             if (int32_t rc = bbp_describe(ctx->members[i], buf + off, cap - off)) return rc;
             off += (uint32_t)strlen(buf + off);
@@ -412,12 +466,18 @@ extern "C" int32_t bbp_describe(bbp_ctx* ctx, char* buf, uint32_t cap) {
         // (the UDS server: the seven prover streams are created first and have a queue each; a few percent better than 16 at saturation), 16 for verification on all four lanes through the device API
         // (1024 per call: 5.2 ms against 7.2 with 8): INTEGRATION.md section 5.  The variable is read when the HIP runtime
         // initialises, i.e. possibly long before bbp_init.
-        if ((!hwq || atoi(hwq) < 8) && off + 1 < cap)
+        const int hst = hw_queues_state();
+        if (off + 1 < cap)
+            off += (uint32_t)snprintf(buf + off, cap - off, "hardware queues: GPU_MAX_HW_QUEUES=%s (%s); scratch: %.2f GiB in %llu allocation(s) since bbp_init\n",
+                                      hwq ? hwq : "unset",
+                                      hst == 2 ? "exported by the library before HIP initialised" : hst == 1 ? "from the caller's environment" : hst == 3 ? "unset and HIP was already initialised" : "?",
+                                      ctx->scratch_bytes / 1073741824.0, (unsigned long long)ctx->scratch_allocs);
+        if ((hst == 3 || !hwq || atoi(hwq) < 8) && off + 1 < cap)
             off += (uint32_t)snprintf(buf + off, cap - off,
-                                      "WARNING: GPU_MAX_HW_QUEUES is %s: export GPU_MAX_HW_QUEUES=8 (prove-dominated use) or 16 (verification on four lanes) "
-                                      "before the process first touches HIP, or streams of this context share hardware queues and serialise (prover up to "
-                                      "~30 %% slower with the default of 4)\n",
-                                      hwq ? hwq : "not set");
+                                      "WARNING: GPU_MAX_HW_QUEUES is %s%s: the HIP runtime reads it once, when it initialises; export GPU_MAX_HW_QUEUES=" BBP_HWQ_DEFAULT
+                                      " before the process first touches HIP (or call bbp_init first: it does so itself), or streams of this context share "
+                                      "hardware queues and serialise (prover up to ~30 %% slower with the default of 4)\n",
+                                      hwq ? hwq : "not set", hst == 3 ? " and HIP was initialised before bbp_init could set it" : "");
         if (free_b < ((size_t)6 << 30) && off + 1 < cap)
             off += (uint32_t)snprintf(buf + off, cap - off, "WARNING: less than 6 GiB of device memory free: a 1024-proof batch needs ~14 GiB of scratch\n");
         return BBP_OK;

@@ -116,7 +116,9 @@ static std::atomic<uint64_t> g_served{0}, g_errors{0}, g_next_id{1};
 static std::atomic<int> g_live{0}, g_inflight{0};
 static int g_max_conn = 65536;
 static volatile sig_atomic_t g_stop = 0;
+static std::atomic<int> g_fatal{0};  // the engine handle reported BBP_ERR_DEVICE: stop accepting, drain, exit non-zero
 static int g_listen_fd = -1;
+constexpr int EXIT_ENGINE_DEAD = 3;
 
 constexpr uint64_t MAX_FRAME = 1u << 16;  // the largest legitimate request (verify, N = 202) is ~ 16 KB; per-connection buffering is bounded by 2 x this
 
@@ -395,7 +397,22 @@ void Reactor::complete(Pending* p) {
     std::unique_ptr<Pending> own(p);
     g_inflight--;
     auto it = conns.find(p->conn_id);
-    if (p->status == BBP_ERR_DEVICE) logf(0, "engine reports a device failure: %s", p->err.c_str());
+    if (p->status == BBP_ERR_DEVICE) {
+        // The engine's health word is sticky: from here on EVERY call on this handle comes back BBP_ERR_DEVICE ("free this context and
+        // create a new one", include/bbp.h).  The request was NOT judged, so a verify gets no 0x00 (that byte means "rejected") and a
+        // prove gets nothing, as for any prove error: the connection is dropped.  The process stops accepting, drains what is in
+        // flight and exits with EXIT_ENGINE_DEAD so that its supervisor starts a fresh one (a process that has initialised the GPU
+        // is never re-exec'ed; re-initialising the pool in place would keep a possibly damaged device mapping).
+        if (!g_fatal.exchange(1)) {
+            logf(0, "engine reports a device failure: %s -- no further requests are accepted; exiting with status %d once in-flight requests have drained",
+                 p->err.c_str(), EXIT_ENGINE_DEAD);
+            g_stop = 1;
+            if (g_listen_fd >= 0) shutdown(g_listen_fd, SHUT_RDWR);
+        }
+        g_errors++;
+        if (it != conns.end()) drop(it->second.get());
+        return;
+    }
     if (it == conns.end()) return;  // the peer went away meanwhile
     Conn* c = it->second.get();
     c->busy = false;
@@ -719,5 +736,5 @@ int main(int argc, char** argv) {
         _exit(1);  // static destructors / HIP teardown under running GPU work can hang or abort
     }
     g_eng.free_(g_eng.ctx);
-    return 0;
+    return g_fatal.load() ? EXIT_ENGINE_DEAD : 0;
 }

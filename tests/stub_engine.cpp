@@ -43,8 +43,18 @@ static bool canonical(const uint8_t* s) {  // < 2^253 is enough for a stub: the 
     return (s[31] & 0xe0) == 0;
 }
 
+// STUB_DEVICE_FAIL_AFTER=n: the n-th combined call and every later one return BBP_ERR_DEVICE (the real engine's sticky health word)
+static std::atomic<int> g_calls{0};
+static bool device_dead(std::string* err) {
+    static const int after = getenv("STUB_DEVICE_FAIL_AFTER") ? atoi(getenv("STUB_DEVICE_FAIL_AFTER")) : 0;
+    if (!after || ++g_calls < after) return false;
+    if (err) *err = "stub: device health flag raised";
+    return true;
+}
+
 namespace bbp {
-int32_t prove_batch_locked(bbp_ctx* ctx, uint32_t B, uint32_t N, const uint8_t* in, const uint8_t*, uint8_t* out, int32_t* status, std::string*) {
+int32_t prove_batch_locked(bbp_ctx* ctx, uint32_t B, uint32_t N, const uint8_t* in, const uint8_t*, uint8_t* out, int32_t* status, std::string* err) {
+    if (device_dead(err)) return BBP_ERR_DEVICE;
     ctx->batch_calls++;
     Inside in_call(ctx, 0);
     static const int prove_us = getenv("STUB_PROVE_US") ? atoi(getenv("STUB_PROVE_US")) : 3000;
@@ -67,7 +77,8 @@ int32_t prove_batch_locked(bbp_ctx* ctx, uint32_t B, uint32_t N, const uint8_t* 
     }
     return BBP_OK;
 }
-int32_t verify_batch_locked(bbp_ctx* ctx, uint32_t B, uint32_t N, uint32_t rec_ver, const uint8_t* in, int32_t* status, std::string*) {
+int32_t verify_batch_locked(bbp_ctx* ctx, uint32_t B, uint32_t N, uint32_t rec_ver, const uint8_t* in, int32_t* status, std::string* err) {
+    if (device_dead(err)) return BBP_ERR_DEVICE;
     ctx->batch_calls++;
     Inside in_call(ctx, 1);
     usleep(1000);

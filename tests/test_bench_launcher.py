@@ -25,6 +25,11 @@ def test_gpus_2_launches_two_ranks_and_prints_one_line():
     assert out["data"] == "stub" and "not a measurement" in out["metric"]
     # whole-job aggregate: units of BOTH ranks over the max-over-ranks time
     assert abs(out["value"] - 2 * 5 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
+    # ... and every rank's own figure beside it (a straggler shows): the slowest rank's time is the step time, no rank is faster than 1/N of `value`
+    pr = out["per_rank"]
+    assert len(pr["value"]) == 2 and len(pr["ms_per_step"]) == 2
+    assert abs(max(pr["ms_per_step"]) - out["ms_per_step"]) < 1e-9 + 1e-6 * out["ms_per_step"]
+    assert all(v >= out["value"] / 2 * (1 - 1e-6) for v in pr["value"])
 
 
 def test_world_size_mismatch_is_refused():

@@ -48,6 +48,16 @@ def test_product_does_not_reference_oracle():
                 assert "oracle/" not in txt and "from oracle" not in txt and "import oracle" not in txt and "bbp_oracle" not in txt, f
 
 
+def test_no_verdict_changing_knobs_in_the_product(bbp):
+    """a knock-out mask read from the environment turned the verifier into accept-stale.  Verdict-changing
+    experiment knobs exist only in -DBBP_EXPERIMENTS builds (tools/build_variant.py); the product library must not even carry
+    their names, neither as getenv strings nor as compile-time knock-outs."""
+    blob = open(bbp.lib_path, "rb").read()
+    for name in (b"BBP_KO_VERIFY", b"BBP_KO_", b"BBP_EXP_ROWMASK"):
+        assert name not in blob, name
+    assert b"BBP_SLICES" in blob  # (the scheduling knobs are there: the scan does see getenv strings)
+
+
 def test_circuit_synthesis_sizes_and_statuses(bbp):
     """Host-only synthesis through the C ABI (no device): n_mul = 1442 + 3N, n_cons = 2 n_mul + 3 + 3N; the states
     the reference panics on / rejects come back as statuses."""
