@@ -259,6 +259,15 @@ class ProveWorkload(_Base):
         self.ent_dev = _to_dev(torch, device, b"".join(self.ents))
         self.rec = bbp.record_size(items)
         self.out_dev = torch.zeros(batch * self.rec, dtype=torch.uint8, device=device)
+        # The timed loop rotates over several DISTINCT input sets (round 4; one set proven 20 times before): set 0 is the one every check,
+        # the exclusive pass and the gather look at (out_dev); sets 1.. have their own bids, entropy and output buffers.  The work is
+        # data-independent apart from NAF digit counts, so the figure does not move -- but no step repeats the previous step's inputs.
+        self.k = 0
+        self.sets = [(self.in_dev, self.ent_dev, self.out_dev)]
+        for j in range(1, max(1, int(os.environ.get("BBP_BENCH_INPUT_SETS", "3")))):
+            ins_j, ents_j, _, _ = synth_bids(ctx, batch, items, seed + 7919 * j)
+            self.sets.append((_to_dev(torch, device, b"".join(ins_j)), _to_dev(torch, device, b"".join(ents_j)),
+                              torch.zeros(batch * self.rec, dtype=torch.uint8, device=device)))
         if hasattr(ctx, "reserve") and not os.environ.get("BBP_BENCH_NO_RESERVE"):
             ctx.reserve(batch, items)  # bbp_reserve: every buffer of every schedule sized before the clock starts (what a server does at start-up)
         self.units_per_step = batch
@@ -279,10 +288,13 @@ class ProveWorkload(_Base):
         self.traffic_key = "prove_b1024_n8" if batch == 1024 and items == 8 else None
         self.config = {"workload": "configs[2]: batch of %d full blind-bid R1CS proves (N=%d, 1466 multipliers, 11 IPA rounds)" % (batch, items),
                        "batch_per_gpu": batch, "bid_list_len": items, "msm_recoding": "NAF-12", "parallelism": "batch-sharded",
-                       "ref_msm_terms_per_proof": ref_terms, "engine_msm_terms_per_proof": engine_terms + 4096}
+                       "ref_msm_terms_per_proof": ref_terms, "engine_msm_terms_per_proof": engine_terms + 4096,
+                       "distinct_input_sets_in_rotation": len(self.sets)}
 
     def step(self, stream):
-        self.ctx.prove_batch_dev(self.B, self.N, self.in_dev.data_ptr(), self.ent_dev.data_ptr(), self.out_dev.data_ptr(), stream)
+        in_dev, ent_dev, out_dev = self.sets[self.k % len(self.sets)]
+        self.k += 1
+        self.ctx.prove_batch_dev(self.B, self.N, in_dev.data_ptr(), ent_dev.data_ptr(), out_dev.data_ptr(), stream)
 
     def records(self):
         return bytes(self.out_dev.cpu().numpy().tobytes())
@@ -292,11 +304,13 @@ class ProveWorkload(_Base):
         w = copy.copy(self)
         w.ctx = ctx2
         w.out_dev = self.torch.zeros_like(self.out_dev)
+        w.sets = [(i, e, w.out_dev if j == 0 else self.torch.zeros_like(o)) for j, (i, e, o) in enumerate(self.sets)]
+        w.k = 0  # its first step proves set 0 into its own out_dev: what same_results compares
         self.torch.cuda.synchronize()  # (zero-fill on torch's stream before another context's stream writes the tensor)
         return w
 
     def same_results(self, other):
-        return bool((self.out_dev == other.out_dev).all())
+        return all(bool((a[2] == b[2]).all()) for a, b in zip(self.sets, other.sets) if bool(b[2].any()) and bool(a[2].any()))
 
     def check(self):
         lib = _oracle_lib()

@@ -275,6 +275,10 @@ inline int32_t dev_reserve(bbp_ctx* ctx, DevBuf& b, size_t bytes) {
     b.cap = want;
     ctx->scratch_bytes += want;
     ctx->scratch_allocs++;  // bbp_describe reports both: after bbp_reserve the count must stand still (tests/test_gpu_boundary.py)
+    static const bool trace = getenv("BBP_TRACE_ALLOC") != nullptr;  // which buffer grew: its offset inside the context names the field
+    if (trace)
+        fprintf(stderr, "[bbp alloc] device %d: buffer at context offset %zu grows to %zu bytes (allocation %llu)\n", ctx->device,
+                (size_t)(reinterpret_cast<const char*>(&b) - reinterpret_cast<const char*>(ctx)), want, (unsigned long long)ctx->scratch_allocs);
     return BBP_OK;
 }
 

@@ -154,6 +154,48 @@ BBP_HD fe fe_carry64_prebiased(i64 (&h)[10]) {
 }
 
 #define BBP_FE_BIAS(k) ((i64)1 << (((k) & 1) ? 24 : 25))  // 2^(bits_k - 1): even columns hold 26 bits, odd ones 25
+// The bias is meant to ride in as the 64-bit addend of the column's FIRST multiply-add (free).  Written as a C sum the compiler
+// reassociates it: the constant is added at the END of the chain with a v_lshl_add_u64 of its own -- ten extra VOP3 instructions per
+// multiplication (3.45 cycles each per SIMD at two waves per SIMD against 4.38 for the multiply-add itself, tools/exp_issue.hip: 5 %
+// of a mixed addition; an operand the optimiser cannot see through is reassociated just the same, and so is a sum whose first
+// term alone is opaque).  So on the device a column is ONE inline-assembly block: v_mad_i64_i32 with the bias from an SGPR pair,
+// then the remaining terms accumulating in place.  One block per column, not one statement per multiply-add: the hazard recogniser
+// pads every pair of adjacent asm statements with an s_nop.  The chain inside a block is dependent, which costs nothing here: one
+// wave alone cannot issue these faster than one per 8.75 cycles whatever their independence, two waves share the SIMD at 4.38.
+// (-DBBP_FE_MAD_C keeps the plain C form for A/B runs.)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BBP_FE_MAD_C)
+#define BBP_FE_MAD_ASM 1
+#define BBP_MAD0 "v_mad_i64_i32 %0, vcc, %2, %3, %1\n\t"
+#define BBP_MADN(a, b) "v_mad_i64_i32 %0, vcc, %" #a ", %" #b ", %0\n\t"
+__device__ __forceinline__ i64 fe_col10(i64 bias, i32 a0, i32 b0, i32 a1, i32 b1, i32 a2, i32 b2, i32 a3, i32 b3, i32 a4, i32 b4, i32 a5, i32 b5, i32 a6,
+                                        i32 b6, i32 a7, i32 b7, i32 a8, i32 b8, i32 a9, i32 b9) {
+    i64 d;
+    asm(BBP_MAD0 BBP_MADN(4, 5) BBP_MADN(6, 7) BBP_MADN(8, 9) BBP_MADN(10, 11) BBP_MADN(12, 13) BBP_MADN(14, 15) BBP_MADN(16, 17) BBP_MADN(18, 19) BBP_MADN(20, 21)
+        : "=&v"(d)
+        : "s"(bias), "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(a6), "v"(b6), "v"(a7),
+          "v"(b7), "v"(a8), "v"(b8), "v"(a9), "v"(b9)
+        : "vcc");
+    return d;
+}
+__device__ __forceinline__ i64 fe_col6(i64 bias, i32 a0, i32 b0, i32 a1, i32 b1, i32 a2, i32 b2, i32 a3, i32 b3, i32 a4, i32 b4, i32 a5, i32 b5) {
+    i64 d;
+    asm(BBP_MAD0 BBP_MADN(4, 5) BBP_MADN(6, 7) BBP_MADN(8, 9) BBP_MADN(10, 11) BBP_MADN(12, 13)
+        : "=&v"(d)
+        : "s"(bias), "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5)
+        : "vcc");
+    return d;
+}
+__device__ __forceinline__ i64 fe_col5(i64 bias, i32 a0, i32 b0, i32 a1, i32 b1, i32 a2, i32 b2, i32 a3, i32 b3, i32 a4, i32 b4) {
+    i64 d;
+    asm(BBP_MAD0 BBP_MADN(4, 5) BBP_MADN(6, 7) BBP_MADN(8, 9) BBP_MADN(10, 11)
+        : "=&v"(d)
+        : "s"(bias), "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4)
+        : "vcc");
+    return d;
+}
+#undef BBP_MAD0
+#undef BBP_MADN
+#endif
 
 // term f_i g_j lands in column (i+j) mod 10, times 19 when i+j >= 10 (2^255 = 19), times 2 when i and j are both odd
 BBP_HD fe fe_mul(const fe& f, const fe& g) {
@@ -164,6 +206,19 @@ BBP_HD fe fe_mul(const fe& f, const fe& g) {
         f2[i] = 2 * f.v[i];
     }
     i64 h[10];
+#ifdef BBP_FE_MAD_ASM
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+        i32 a[10], b[10];  // column k: terms (i, j) with i + j = k or k + 10
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+            const int j = (k - i + 10) % 10;
+            a[i] = ((i & 1) && (j & 1)) ? f2[i] : f.v[i];
+            b[i] = (i + j >= 10) ? g19[j] : g.v[j];
+        }
+        h[k] = fe_col10(BBP_FE_BIAS(k), a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5], a[6], b[6], a[7], b[7], a[8], b[8], a[9], b[9]);
+    }
+#else
 #pragma unroll
     for (int k = 0; k < 10; k++) h[k] = BBP_FE_BIAS(k);
 #pragma unroll
@@ -176,10 +231,24 @@ BBP_HD fe fe_mul(const fe& f, const fe& g) {
             h[k % 10] += (i64)fi * gj;
         }
     }
+#endif
     return fe_carry64_prebiased(h);
 }
 
 // dedicated squaring: 55 multiplies (off-diagonal terms once, doubled)
+// coefficient of f_i f_j (i <= j, k = i + j): (i == j ? 1 : 2) * (both odd ? 2 : 1) * (k >= 10 ? 19 : 1); the factors are split so that every
+// 32-bit operand stays below 2^31: 2 goes on f_i, 19 / 38 on f_j (38 only for odd j)
+#define BBP_SQ_TERM(i, j, a, b)                                                                                       \
+    do {                                                                                                              \
+        const bool both_odd_ = ((i) & 1) && ((j) & 1);                                                                \
+        if ((i) == (j)) {                                                                                             \
+            a = both_odd_ ? f2[i] : f.v[i];                                                                           \
+            b = ((i) + (j) >= 10) ? f19[j] : f.v[j];                                                                  \
+        } else {                                                                                                      \
+            a = f2[i];                                                                                                \
+            b = both_odd_ ? (((i) + (j) >= 10) ? f38[j] : f2[j]) : (((i) + (j) >= 10) ? f19[j] : f.v[j]);             \
+        }                                                                                                             \
+    } while (0)
 BBP_HD void fe_sq_columns(const fe& f, i64 (&h)[10]) {
     i32 f2[10], f19[10], f38[10];
 #pragma unroll
@@ -188,31 +257,47 @@ BBP_HD void fe_sq_columns(const fe& f, i64 (&h)[10]) {
         f19[i] = 19 * f.v[i];
         f38[i] = 38 * f.v[i];
     }
+#ifdef BBP_FE_MAD_ASM
+    // by column (fe_col5 / fe_col6 above): even columns have six terms, odd ones five; the bias rides in the first multiply-add
+#pragma unroll
+    for (int c = 0; c < 10; c++) {
+        i32 a[6] = {0, 0, 0, 0, 0, 0}, b[6] = {0, 0, 0, 0, 0, 0};
+        int n = 0;
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+#pragma unroll
+            for (int j = i; j < 10; j++) {
+                if ((i + j) % 10 != c) continue;
+                i32 aa, bb;
+                BBP_SQ_TERM(i, j, aa, bb);
+                a[n] = aa;
+                b[n] = bb;
+                n++;
+            }
+        }
+        h[c] = (c & 1) ? fe_col5(BBP_FE_BIAS(c), a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4])
+                       : fe_col6(BBP_FE_BIAS(c), a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5]);
+    }
+#else
 #pragma unroll
     for (int i = 0; i < 10; i++) {
 #pragma unroll
         for (int j = i; j < 10; j++) {
-            const int k = i + j;
-            const bool both_odd = (i & 1) && (j & 1);
-            // coefficient of f_i f_j: (i == j ? 1 : 2) * (both_odd ? 2 : 1) * (k >= 10 ? 19 : 1)
-            // factors are split so that every 32-bit operand stays below 2^31: 2 goes on f_i, 19 / 38 on f_j (38 only for odd j)
             i32 a, b;
-            if (i == j) {
-                a = both_odd ? f2[i] : f.v[i];
-                b = (k >= 10) ? f19[j] : f.v[j];
-            } else {
-                a = f2[i];
-                b = both_odd ? ((k >= 10) ? f38[j] : f2[j]) : ((k >= 10) ? f19[j] : f.v[j]);
-            }
-            h[k % 10] += (i64)a * b;
+            BBP_SQ_TERM(i, j, a, b);
+            h[(i + j) % 10] += (i64)a * b;
         }
     }
+#endif
 }
+#undef BBP_SQ_TERM
 
 BBP_HD fe fe_sq(const fe& f) {
     i64 h[10];
+#ifndef BBP_FE_MAD_ASM
 #pragma unroll
     for (int k = 0; k < 10; k++) h[k] = BBP_FE_BIAS(k);
+#endif
     fe_sq_columns(f, h);
     return fe_carry64_prebiased(h);
 }

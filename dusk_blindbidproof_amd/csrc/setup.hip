@@ -208,6 +208,15 @@ static int32_t init_body(int32_t device, bbp_ctx** out) {
         const char* hm = getenv("BBP_BATCH_HOLD_MARGIN_US");  // -1 = off
         static_cast<Combiner*>(ctx->combiner)->set_hold(hm ? atoi(hm) : 4000, 40000u, 48.0);  // ~40 ms opening stage, ~48 us per proof
     }
+    if (getenv("BBP_TRACE_ALLOC")) {  // the field map that goes with dev_reserve's "[bbp alloc] ... context offset" lines
+#define BBP_OFF(f) (size_t)(reinterpret_cast<const char*>(&ctx->f) - reinterpret_cast<const char*>(ctx))
+        fprintf(stderr, "[bbp alloc] field offsets: scal %zu idx %zu sorted %zu pts %zu enc %zu batch[0] %zu (+%zu each, %d prover then %d verifier) io_in %zu raw[0] %zu "
+                        "slice_sorted[0] %zu slice_pts[0] %zu slice_fold[0] %zu slice_vtab[0] %zu vl[0].misc %zu vl[0].agg %zu vl[1].misc %zu io[0].in %zu io[1].in %zu\n",
+                BBP_OFF(scal), BBP_OFF(idx), BBP_OFF(sorted), BBP_OFF(pts), BBP_OFF(enc), BBP_OFF(batch[0]), sizeof(bbp::DevBuf), (int)bbp_ctx::PROVE_BUFS, (int)bbp_ctx::VLANES,
+                BBP_OFF(io_in), BBP_OFF(raw[0]), BBP_OFF(slice_sorted[0]), BBP_OFF(slice_pts[0]), BBP_OFF(slice_fold[0]), BBP_OFF(slice_vtab[0]), BBP_OFF(vl[0].misc),
+                BBP_OFF(vl[0].agg), BBP_OFF(vl[1].misc), BBP_OFF(io[0].in), BBP_OFF(io[1].in));
+#undef BBP_OFF
+    }
     BBP_HIP_TRY(ctx, hipSetDevice(device));
     hipDeviceProp_t prop;
     BBP_HIP_TRY(ctx, hipGetDeviceProperties(&prop, device));

@@ -7,6 +7,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# Every test process runs the engine with its device-affinity assertion on (csrc/context.h device_affinity_ok): a HIP call made for a
+# context while another device is current fails the call instead of passing silently on a one-GPU box.
+os.environ.setdefault("BBP_DEBUG_DEVICE_CHECK", "1")
 
 
 def pytest_configure(config):

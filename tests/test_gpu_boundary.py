@@ -250,3 +250,81 @@ def test_describe_reports_device_and_warns_about_hardware_queues(ctx, bbp):
     assert "gfx950" in text and "CUs" in text and "verifier: 4 lanes" in text
     hwq = os.environ.get("GPU_MAX_HW_QUEUES")
     assert ("WARNING: GPU_MAX_HW_QUEUES" in text) == (hwq is None or int(hwq) < 8)
+    assert "hardware queues: GPU_MAX_HW_QUEUES=" in text and "allocation(s) since bbp_init" in text
+
+
+_HWQ_PROBE = r"""
+import ctypes, os, sys
+pre = sys.argv[2]
+if pre == "hip_first":  # some other component of the host process touched HIP before the engine was created
+    hip = ctypes.CDLL("libamdhip64.so", mode=ctypes.RTLD_GLOBAL)
+    n = ctypes.c_int(0)
+    assert hip.hipGetDeviceCount(ctypes.byref(n)) == 0 and n.value >= 1
+L = ctypes.CDLL(sys.argv[1])
+h = ctypes.c_void_p()
+L.bbp_init.argtypes = [ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)]
+assert L.bbp_init(0, ctypes.byref(h)) == 0
+buf = ctypes.create_string_buffer(8192)
+L.bbp_describe.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint32]
+assert L.bbp_describe(h, buf, 8192) == 0
+libc = ctypes.CDLL(None)
+libc.getenv.restype = ctypes.c_char_p
+print("ENV", libc.getenv(b"GPU_MAX_HW_QUEUES"))
+print(buf.value.decode())
+L.bbp_free.argtypes = [ctypes.c_void_p]
+L.bbp_free(h)
+"""
+
+
+def test_library_owns_the_hardware_queue_setting(bbp):
+    """a Rust / Go / C host bound per INTEGRATION.md knows nothing about GPU_MAX_HW_QUEUES.  bbp_init exports
+    it itself when the process has not initialised HIP yet, leaves a caller's own value alone, and WARNs through bbp_describe when
+    something else initialised HIP first with the variable unset.  Each case is a fresh process that loads only libbbp_hip.so."""
+    import os
+    import subprocess
+    import sys
+
+    def probe(pre, env_extra):
+        env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+        env.update(env_extra)
+        p = subprocess.run([sys.executable, "-c", _HWQ_PROBE, bbp.lib_path, pre], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        return p.stdout
+    out = probe("engine_first", {})
+    assert "ENV b'16'" in out and "exported by the library before HIP initialised" in out and "WARNING: GPU_MAX_HW_QUEUES" not in out, out
+    out = probe("engine_first", {"GPU_MAX_HW_QUEUES": "8"})
+    assert "ENV b'8'" in out and "from the caller's environment" in out and "WARNING: GPU_MAX_HW_QUEUES" not in out, out
+    out = probe("hip_first", {})
+    assert "ENV None" in out and "HIP was initialised before bbp_init could set it" in out, out
+
+
+def _allocs(c):
+    import re
+    m = re.search(r"in (\d+) allocation\(s\) since bbp_init", c.describe())
+    assert m
+    return int(m.group(1))
+
+
+def test_reserve_below_1024_leaves_nothing_to_allocate(bbp, oc):
+    """bbp_reserve(max_batch < 1024) used to warm three of the five rotating prover buffers; the 4th / 5th call under
+    load then grew its buffer with hipFree + hipMalloc (a 0.1-1 s stall for everybody).  After the reservation, seven consecutive
+    prove calls and five verify calls of that size -- every buffer of the rotation, every staging slot, every verifier lane --
+    perform no scratch allocation at all; the records are still the oracle's."""
+    N, B = 8, 192
+    c = bbp.Context(0)
+    try:
+        c.reserve(B, N)
+        ins, ents, vins = _synth_batch(c, B, N, seed=4242)  # (bbp_witness_batch has staging of its own: not what is counted here)
+        a0 = _allocs(c)
+        assert a0 > 0
+        exp, est = oc.prove_many(b"".join(ins), b"".join(ents), B, N, threads=8)
+        for k in range(7):
+            out, st = c.prove_batch(B, N, b"".join(ins), b"".join(ents))
+            assert st == [0] * B and out == exp, k
+        rs_ = bbp.record_size(N)
+        vin = b"".join(exp[i * rs_:(i + 1) * rs_] + b"".join(vins[i]) for i in range(B))
+        for k in range(5):
+            assert c.verify_batch(B, N, vin) == [0] * B
+        assert _allocs(c) == a0, (a0, _allocs(c))
+    finally:
+        c.close()

@@ -546,6 +546,55 @@ def test_pipelined_calls_with_different_list_lengths(ctx, oc, bbp):
         assert bytes(out.cpu().numpy().tobytes()) == solo, it
 
 
+def test_config3_all_1024_records_under_both_schedules(bbp, oc, capfd):
+    """BASELINE configs[2] at its stated size with EVERY record checked (20 of 1024 were): six device calls of 1024
+    proofs (N = 8) back to back.  The first finds an idle device and is cut into three slices; from the fourth on three earlier calls
+    are in flight and whole calls run in rotation over five buffers (prover.hip "deep": the schedule behind the headline number).
+    The engine's own trace must show both paths, and all 1024 records of a sliced call AND of a rotating call must equal what the C
+    oracle proves from the same inputs and entropy (~25 s of oracle time on the box's cores)."""
+    import os
+    import torch
+    dev = torch.device("cuda", 0)
+    old = os.environ.get("BBP_TRACE_PROVE")
+    os.environ["BBP_TRACE_PROVE"] = "1"
+    try:
+        c2 = bbp.Context(0)
+    finally:
+        if old is None:
+            os.environ.pop("BBP_TRACE_PROVE", None)
+        else:
+            os.environ["BBP_TRACE_PROVE"] = old
+    try:
+        B, N = 1024, 8
+        rs_ = bbp.record_size(N)
+        ins, ents, _ = _synth_batch(c2, B, N, seed=31337)
+        exp, est = oc.prove_many(b"".join(ins), b"".join(ents), B, N, threads=os.cpu_count() or 8)
+        assert est == [0] * B
+        d_in = torch.frombuffer(bytearray(b"".join(ins)), dtype=torch.uint8).to(dev)
+        d_ent = torch.frombuffer(bytearray(b"".join(ents)), dtype=torch.uint8).to(dev)
+        torch.cuda.synchronize()
+        capfd.readouterr()
+        s = torch.cuda.current_stream().cuda_stream
+        outs = []
+        for it in range(6):
+            out = torch.zeros(B * rs_, dtype=torch.uint8, device=dev)
+            c2.prove_batch_dev(B, N, d_in.data_ptr(), d_ent.data_ptr(), out.data_ptr(), s)
+            outs.append(out)
+        torch.cuda.synchronize()
+        trace = [l for l in capfd.readouterr().err.splitlines() if l.startswith("prove call")]
+        assert len(trace) == 6, trace
+        sliced = [i for i, l in enumerate(trace) if " deep 0 " in l and " rotate 0 " in l]
+        rotating = [i for i, l in enumerate(trace) if " deep 1 " in l and " rotate 1 " in l]
+        assert sliced and sliced[0] == 0 and rotating, trace
+        for which in (sliced[0], rotating[-1]):
+            got = bytes(outs[which].cpu().numpy().tobytes())
+            bad = [i for i in range(B) if got[i * rs_:(i + 1) * rs_] != exp[i * rs_:(i + 1) * rs_]]
+            assert not bad, (which, trace[which], bad[:10])
+        assert c2.health() == 0
+    finally:
+        c2.close()
+
+
 def test_config3_full_batch(ctx, oc, bbp):
     """SURVEY.md 8d config 3 at full size: 1024 full proves (N = 8) in one batch call; the first 16 and the last 4 records
     byte-compared with the C oracle under the same entropy, every proof accepted by the device verifier, a spread sample of 48

@@ -5,12 +5,14 @@
                        [--steps 20 --warmup 4] [--exclusive] [--tag NAME] [--commit SHA] [--out gpurun_out/ab/NAME.jsonl]
     python tools/ab.py --knob variant --values - coop            # "-" = the product library, others = tools/build_variant.py builds
     python tools/ab.py --knob "BBP_A,BBP_B" --values 1,0 0,1      # several environment knobs moved together
+    python tools/ab.py --harness uds --knob hwq --values 8 16 --bench "--connections 3072 --no-verify --ops 110592"   # through the UDS server
+    python tools/ab.py --harness script --script tools/midsize.py --knob BBP_RNG_DPP --values 1 0 --bench "256"         # any other tool
 
-Arms alternate inside every repeat (a b a b ...), so box drift and clock state hit both alike.  Every run is one bench.py child
-process (fresh context); one JSON object per run goes to the jsonl with the box id, the commit given on the command line, the arm,
-and the figures that were being compared by hand before: value, ms_per_step, roofline.alu, roofline.exclusive, per-kernel averages.
-A summary table (median per arm) is printed at the end.  Nothing here touches oracle/ beyond bench.py's own sampled check
-(BBP_BENCH_NO_CHECK=1 is set only with --no-check, for deliberately wrong knock-out builds)."""
+Arms alternate inside every repeat (a b a b ...), so box drift and clock state hit both alike.  Every run is one child process
+(fresh context); one JSON object per run goes to the jsonl with the box id, the commit given on the command line, the arm, and the
+figures that were being compared by hand before: value, ms_per_step, roofline.alu, roofline.exclusive, per-kernel averages (bench.py),
+or the tool's own JSON line (uds / script).  A summary table (median per arm) is printed at the end.  Nothing here touches oracle/
+beyond bench.py's own sampled check (BBP_BENCH_NO_CHECK=1 is set only with --no-check, for deliberately wrong knock-out builds)."""
 import argparse, json, os, socket, statistics, subprocess, sys, time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -39,7 +41,11 @@ def main():
     ap.add_argument("--knob", required=True, help="environment variable name(s, comma separated), or 'variant' for BBP_LIB_VARIANT builds")
     ap.add_argument("--values", nargs="+", required=True)
     ap.add_argument("--repeats", type=int, default=3)
-    ap.add_argument("--bench", default="", help="extra bench.py arguments (workload, batch)")
+    ap.add_argument("--harness", default="bench", choices=["bench", "uds", "script"],
+                    help="what one run is: bench.py (default); tools/uds_bench.py (the UDS server + load generator; knob 'hwq' = its --hwq); "
+                         "or any python tool given with --script (its stdout lines are kept)")
+    ap.add_argument("--script", default=None, help="--harness script: the tool, e.g. tools/midsize.py")
+    ap.add_argument("--bench", default="", help="extra arguments of the harness (bench.py: workload, batch; uds_bench.py: --connections ...; script: its own)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--exclusive", action="store_true", help="keep bench.py's exclusive (one-slice) pass: roofline.exclusive per run")
@@ -68,12 +74,20 @@ def main():
                         env[k] = v
                 if a.no_check:
                     env["BBP_BENCH_NO_CHECK"] = "1"
-                cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(a.steps), "--warmup", str(a.warmup), "--no-cpu-baseline", "--no-build"]
-                if not a.exclusive:
-                    cmd.append("--no-exclusive")
-                if not a.also:
-                    cmd.append("--no-also")
-                cmd += a.bench.split()
+                if a.harness == "bench":
+                    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(a.steps), "--warmup", str(a.warmup), "--no-cpu-baseline", "--no-build"]
+                    if not a.exclusive:
+                        cmd.append("--no-exclusive")
+                    if not a.also:
+                        cmd.append("--no-also")
+                    cmd += a.bench.split()
+                elif a.harness == "uds":
+                    cmd = [sys.executable, os.path.join(ROOT, "tools", "uds_bench.py")] + a.bench.split()
+                    if a.knob == "hwq":  # the server process's GPU_MAX_HW_QUEUES is uds_bench.py's own flag
+                        env.pop("hwq", None)
+                        cmd += ["--hwq", val]
+                else:
+                    cmd = [sys.executable, os.path.join(ROOT, a.script)] + a.bench.split()
                 t0 = time.time()
                 try:
                     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=a.timeout)
@@ -84,7 +98,17 @@ def main():
                     d, err = None, "timeout"
                 rec = {"tag": tag, "knob": a.knob, "arm": val, "repeat": rep, "box": box, "commit": a.commit, "bench": a.bench, "steps": a.steps,
                        "wall_s": round(time.time() - t0, 1)}
-                if d:
+                if d and a.harness != "bench":  # uds_bench.py / a script: keep its own line(s)
+                    rec["result"] = d
+                    rec["value"] = d.get("proofs_per_s") or d.get("value") or 0.0   # the load generator's whole-run rate
+                    rec["unit"] = "proofs/s (through the socket)" if "proofs_per_s" in d else d.get("unit", "")
+                    rec["ms_per_step"] = (d.get("prove_latency_ms") or {}).get("p50") or d.get("ms_per_step") or 0.0  # prove p50 for the UDS harness
+                elif a.harness == "script" and not d:
+                    rec["stdout_tail"] = p.stdout.decode()[-1500:]
+                    rec.pop("error", None)
+                    err = None
+                    d = {}
+                elif d:
                     rl = d.get("roofline") or {}
                     rec.update({"value": d["value"], "unit": d.get("unit"), "ms_per_step": d["ms_per_step"],
                                 "alu_frac": (rl.get("alu") or {}).get("frac"), "whole_step_frac": (rl.get("alu") or {}).get("whole_step_frac"),
