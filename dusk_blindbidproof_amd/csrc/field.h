@@ -165,6 +165,9 @@ BBP_HD fe fe_carry64_prebiased(i64 (&h)[10]) {
 // (-DBBP_FE_MAD_C keeps the plain C form for A/B runs.)
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(BBP_FE_MAD_C)
 #define BBP_FE_MAD_ASM 1
+#ifndef BBP_FE_NO_CHAIN
+#define BBP_FE_CHAIN 1  // carries threaded through the column sums (below): measured 21.30 k against 20.88 k proofs/s, exclusive accumulate time -4.5 %
+#endif
 #define BBP_MAD0 "v_mad_i64_i32 %0, vcc, %2, %3, %1\n\t"
 #define BBP_MADN(a, b) "v_mad_i64_i32 %0, vcc, %" #a ", %" #b ", %0\n\t"
 __device__ __forceinline__ i64 fe_col10(i64 bias, i32 a0, i32 b0, i32 a1, i32 b1, i32 a2, i32 b2, i32 a3, i32 b3, i32 a4, i32 b4, i32 a5, i32 b5, i32 a6,
@@ -193,8 +196,50 @@ __device__ __forceinline__ i64 fe_col5(i64 bias, i32 a0, i32 b0, i32 a1, i32 b1,
         : "vcc");
     return d;
 }
+#define BBP_MAD0V "v_mad_i64_i32 %0, vcc, %2, %3, %1\n\t"
+// the same with the first addend in a VGPR pair (the carry of the previous column: BBP_FE_CHAIN)
+__device__ __forceinline__ i64 fe_col10v(i64 addend, i32 a0, i32 b0, i32 a1, i32 b1, i32 a2, i32 b2, i32 a3, i32 b3, i32 a4, i32 b4, i32 a5, i32 b5, i32 a6,
+                                         i32 b6, i32 a7, i32 b7, i32 a8, i32 b8, i32 a9, i32 b9) {
+    i64 d;
+    asm(BBP_MAD0V BBP_MADN(4, 5) BBP_MADN(6, 7) BBP_MADN(8, 9) BBP_MADN(10, 11) BBP_MADN(12, 13) BBP_MADN(14, 15) BBP_MADN(16, 17) BBP_MADN(18, 19) BBP_MADN(20, 21)
+        : "=&v"(d)
+        : "v"(addend), "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(a6), "v"(b6), "v"(a7),
+          "v"(b7), "v"(a8), "v"(b8), "v"(a9), "v"(b9)
+        : "vcc");
+    return d;
+}
+__device__ __forceinline__ i64 fe_col5v(i64 addend, i32 a0, i32 b0, i32 a1, i32 b1, i32 a2, i32 b2, i32 a3, i32 b3, i32 a4, i32 b4) {
+    i64 d;
+    asm(BBP_MAD0V BBP_MADN(4, 5) BBP_MADN(6, 7) BBP_MADN(8, 9) BBP_MADN(10, 11)
+        : "=&v"(d)
+        : "v"(addend), "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4)
+        : "vcc");
+    return d;
+}
+#undef BBP_MAD0V
 #undef BBP_MAD0
 #undef BBP_MADN
+// BBP_FE_CHAIN (default; -DBBP_FE_NO_CHAIN for the separate carry pass): the carry pass threaded THROUGH the column sums.  Columns are summed in order; an even column's seed constant is its own
+// rounding bias plus the next (odd) column's bias shifted up by its 26 bits, so that its carry h >> 26 already contains that bias and can
+// be the FIRST ADDEND of the odd column's chain (free); the odd column's carry is added to the next even column with one 64-bit add.  Four
+// explicit 64-bit adds per multiplication instead of nine, and no second visit of columns 4 and 0 beyond the wrap (19 c9 into limb 0).
+// The carry order differs from fe_carry64_prebiased, so limbs may differ -- the field element does not (every output is carried).
+constexpr i64 FE_SEED_EVEN = ((i64)1 << 25) + ((i64)1 << 50);
+__device__ __forceinline__ void fe_chain_step(fe& r, i64& c, int k, i64 hk) {  // hk: column k with its seed / carry-in already inside
+    if (k & 1) {
+        c = hk >> 25;
+        r.v[k] = (i32)((u32)hk & ((1u << 25) - 1u)) - (i32)(1u << 24);
+    } else {
+        c = hk >> 26;  // (for k < 9 this carries the next column's rounding bias with it)
+        r.v[k] = (i32)((u32)hk & ((1u << 26) - 1u)) - (i32)(1u << 25);
+    }
+}
+__device__ __forceinline__ void fe_chain_wrap(fe& r, i64 c9) {  // column 9 wraps to column 0 times 19, then one small carry 0 -> 1
+    const i64 x0 = (i64)r.v[0] + 19 * c9;
+    const i64 c = (x0 + ((i64)1 << 25)) >> 26;
+    r.v[0] = (i32)(x0 - (c << 26));
+    r.v[1] += (i32)c;
+}
 #endif
 
 // term f_i g_j lands in column (i+j) mod 10, times 19 when i+j >= 10 (2^255 = 19), times 2 when i and j are both odd
@@ -205,6 +250,32 @@ BBP_HD fe fe_mul(const fe& f, const fe& g) {
         g19[i] = 19 * g.v[i];
         f2[i] = 2 * f.v[i];
     }
+#if defined(BBP_FE_MAD_ASM) && defined(BBP_FE_CHAIN)
+    {
+        fe r;
+        i64 c = 0;
+#pragma unroll
+        for (int k = 0; k < 10; k++) {
+            i32 a[10], b[10];
+#pragma unroll
+            for (int i = 0; i < 10; i++) {
+                const int j = (k - i + 10) % 10;
+                a[i] = ((i & 1) && (j & 1)) ? f2[i] : f.v[i];
+                b[i] = (i + j >= 10) ? g19[j] : g.v[j];
+            }
+            i64 hk;
+            if (k & 1)
+                hk = fe_col10v(c, a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5], a[6], b[6], a[7], b[7], a[8], b[8], a[9], b[9]);
+            else {
+                hk = fe_col10(FE_SEED_EVEN, a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5], a[6], b[6], a[7], b[7], a[8], b[8], a[9], b[9]);
+                if (k) hk += c;
+            }
+            fe_chain_step(r, c, k, hk);
+        }
+        fe_chain_wrap(r, c);
+        return r;
+    }
+#endif
     i64 h[10];
 #ifdef BBP_FE_MAD_ASM
 #pragma unroll
@@ -290,9 +361,52 @@ BBP_HD void fe_sq_columns(const fe& f, i64 (&h)[10]) {
     }
 #endif
 }
-#undef BBP_SQ_TERM
+
+#if defined(BBP_FE_MAD_ASM) && defined(BBP_FE_CHAIN)
+__device__ __forceinline__ fe fe_sq_chain(const fe& f) {
+    i32 f2[10], f19[10], f38[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        f2[i] = 2 * f.v[i];
+        f19[i] = 19 * f.v[i];
+        f38[i] = 38 * f.v[i];
+    }
+    fe r;
+    i64 c = 0;
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+        i32 a[6] = {0, 0, 0, 0, 0, 0}, b[6] = {0, 0, 0, 0, 0, 0};
+        int n = 0;
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+#pragma unroll
+            for (int j = i; j < 10; j++) {
+                if ((i + j) % 10 != k) continue;
+                i32 aa, bb;
+                BBP_SQ_TERM(i, j, aa, bb);
+                a[n] = aa;
+                b[n] = bb;
+                n++;
+            }
+        }
+        i64 hk;
+        if (k & 1)
+            hk = fe_col5v(c, a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4]);
+        else {
+            hk = fe_col6(FE_SEED_EVEN, a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5]);
+            if (k) hk += c;
+        }
+        fe_chain_step(r, c, k, hk);
+    }
+    fe_chain_wrap(r, c);
+    return r;
+}
+#endif
 
 BBP_HD fe fe_sq(const fe& f) {
+#if defined(BBP_FE_MAD_ASM) && defined(BBP_FE_CHAIN)
+    return fe_sq_chain(f);
+#endif
     i64 h[10];
 #ifndef BBP_FE_MAD_ASM
 #pragma unroll
@@ -301,6 +415,8 @@ BBP_HD fe fe_sq(const fe& f) {
     fe_sq_columns(f, h);
     return fe_carry64_prebiased(h);
 }
+
+#undef BBP_SQ_TERM
 
 // 2 * f^2, carried (point doubling needs it inside the multiply bounds)
 BBP_HD fe fe_sq2(const fe& f) {

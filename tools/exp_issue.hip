@@ -9,7 +9,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
-typedef unsigned int u32;
+#include "../dusk_blindbidproof_amd/csrc/point.h"
+using bbp::u32;
 typedef unsigned long long u64;
 
 #define REP8(x) x x x x x x x x
@@ -18,7 +19,7 @@ typedef unsigned long long u64;
     REP8(OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7))
 
 #define K_BEGIN(name)                                                                                                      \
-    __global__ __launch_bounds__(512) void name(u32 iters, u64* out, u32 seed) {                                           \
+    __global__ __launch_bounds__(1024) void name(u32 iters, u64* out, u32 seed) {                                           \
         u32 a[8], b[8];                                                                                                    \
         u64 w[8];                                                                                                          \
         for (int i = 0; i < 8; i++) {                                                                                      \
@@ -105,6 +106,47 @@ DEF(k_mul_f64, OP_MUL_F64)
 DEF(k_cvt_f64_u32, OP_CVT_F64_U32)
 DEF(k_mad_then_add, OP_MAD_MIX)
 
+// the real thing: field.h's multiplication (two dependent chains per lane, as in a mixed addition's independent products) and the
+// real mixed addition against a row the compiler cannot see through -- cycles per OPERATION per SIMD against waves per SIMD
+__global__ __launch_bounds__(1024) void k_fe_mul(u32 iters, u64* out, u32 seed) {
+    using bbp::fe; using bbp::fe_mul; using bbp::i32;
+    fe a = bbp::fe_d(), b = bbp::fe_sqrt_m1(), c = bbp::fe_d2(), d = bbp::fe_sqrt_ad_minus_one();
+    a.v[0] ^= (i32)(threadIdx.x & 0xffff) ^ (i32)(seed & 0xff);
+    c.v[1] ^= (i32)(threadIdx.x & 0xffff);
+    const u64 t0 = __builtin_amdgcn_s_memtime();
+    for (u32 it = 0; it < iters; it++) {
+        a = fe_mul(a, b);
+        c = fe_mul(c, d);
+        b = fe_mul(b, a);
+        d = fe_mul(d, c);
+    }
+    const u64 t1 = __builtin_amdgcn_s_memtime();
+    if ((u32)(a.v[0] ^ b.v[3] ^ c.v[5] ^ d.v[7]) == 0x12345678u) out[1] = 1;
+    if ((threadIdx.x & 63) == 0) out[2 + (threadIdx.x >> 6)] = t1 - t0;
+}
+__global__ __launch_bounds__(1024) void k_ge_madd(u32 iters, u64* out, u32 seed) {
+    using bbp::ge; using bbp::ge_niels; using bbp::i32;
+    ge p = bbp::ge_basepoint();
+    p.X.v[0] ^= (i32)(threadIdx.x & 0xffff) ^ (i32)(seed & 0xff);
+    ge_niels n;
+    n.ypx = bbp::fe_d();
+    n.ymx = bbp::fe_d2();
+    n.xy2d = bbp::fe_sqrt_m1();
+    const u64 t0 = __builtin_amdgcn_s_memtime();
+    for (u32 it = 0; it < iters; it++) {
+#pragma unroll
+        for (int k = 0; k < 10; k++) {
+            asm volatile("" : "+v"(n.ypx.v[k]));
+            asm volatile("" : "+v"(n.ymx.v[k]));
+            asm volatile("" : "+v"(n.xy2d.v[k]));
+        }
+        p = bbp::ge_madd(p, n);
+    }
+    const u64 t1 = __builtin_amdgcn_s_memtime();
+    if ((u32)(p.X.v[0] ^ p.T.v[2]) == 0x12345678u) out[1] = 1;
+    if ((threadIdx.x & 63) == 0) out[2 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
 struct Entry {
     const char* name;
     void (*fn)(u32, u64*, u32);
@@ -121,15 +163,16 @@ int main() {
         {"v_pk_add_u16", k_pk_add_u16, 1}, {"v_pk_mul_lo_u16", k_pk_mul_lo_u16, 1}, {"v_pk_mad_u16", k_pk_mad_u16, 1}, {"v_dot2_u32_u16", k_dot2_u32_u16, 1},
         {"v_dot4_u32_u8", k_dot4_u32_u8, 1}, {"v_fma_f64", k_fma_f64, 1}, {"v_fma_f32", k_fma_f32, 1}, {"v_pk_fma_f32", k_pk_fma_f32, 1}, {"v_mul_f64", k_mul_f64, 1},
         {"v_cvt_f64_u32", k_cvt_f64_u32, 1}, {"v_mad_i64_i32 ; v_add_u32 (alternating)", k_mad_then_add, 2},
+        {"fe_mul (cycles per multiplication / 256)", k_fe_mul, -4}, {"ge_madd, fresh row (cycles per addition / 256)", k_ge_madd, -1},
     };
     u64* d;
     if (hipMalloc(&d, 64 * sizeof(u64)) != hipSuccess) return 1;
     const u32 iters = 2000;
-    printf("%-44s %12s %12s %12s\n", "instruction", "1 wave/SIMD", "2 waves/SIMD", "(cycles per wave-instruction per SIMD)");
+    printf("%-44s %9s %9s %9s %9s   (cycles per wave-instruction per SIMD at 1 / 2 / 3 / 4 waves per SIMD)\n", "instruction", "1", "2", "3", "4");
     for (const Entry& e : tab) {
-        double res[2];
-        for (int two = 0; two < 2; two++) {
-            const int threads = two ? 512 : 256;  // one workgroup on one CU: 4 or 8 wavefronts = 1 or 2 per SIMD
+        double res[4];
+        for (int wps = 1; wps <= 4; wps++) {
+            const int threads = 256 * wps;  // one workgroup on one CU: 4 wavefronts per wave-per-SIMD
             u64 h[64] = {0};
             (void)hipMemset(d, 0, sizeof h);
             hipLaunchKernelGGL(e.fn, dim3(1), dim3(threads), 0, 0, iters / 10, d, 12345u);  // warm-up (clocks, instruction cache)
@@ -143,10 +186,12 @@ int main() {
             const int waves = threads / 64;
             for (int w = 0; w < waves; w++) sum += (double)h[2 + w];
             const double per_wave = sum / waves;                       // cycles of one wave's loop
-            const double insts = (double)iters * 64.0 * e.per_macro;   // wave-instructions one wave issued
-            res[two] = per_wave / insts / (two ? 2.0 : 1.0);           // per SIMD: two waves share it
+            // wave-instructions one wave issued; the two real-code kernels (per_macro < 0) run |per_macro| operations per loop trip and are
+            // reported per operation, scaled by 1 / 256 to sit in the same column format
+            const double insts = e.per_macro > 0 ? (double)iters * 64.0 * e.per_macro : (double)iters * (double)(-e.per_macro) * 256.0;
+            res[wps - 1] = per_wave / insts / wps;                     // per SIMD: the co-resident waves share it
         }
-        printf("%-44s %12.2f %12.2f\n", e.name, res[0], res[1]);
+        printf("%-44s %9.2f %9.2f %9.2f %9.2f\n", e.name, res[0], res[1], res[2], res[3]);
     }
     (void)hipFree(d);
     return 0;
