@@ -91,7 +91,7 @@ BBP_HD ge ge_add(const ge& p, const ge& q) {
     ge r;
     r.X = fe_mul(e, f);
     r.Y = fe_mul(g, h);
-    r.Z = fe_mul(f, g);
+    r.Z = fe_mul(g, f);  // (g first: the four products then share 2 x {e, g} and 19 x {f, h})
     r.T = fe_mul(e, h);
     return r;
 }
@@ -108,7 +108,7 @@ BBP_HD ge ge_madd(const ge& p, const ge_niels& q) {
     ge r;
     r.X = fe_mul(e, f);
     r.Y = fe_mul(g, h);
-    r.Z = fe_mul(f, g);
+    r.Z = fe_mul(g, f);  // (g first: the four products then share 2 x {e, g} and 19 x {f, h})
     r.T = fe_mul(e, h);
     return r;
 }
@@ -123,7 +123,7 @@ BBP_HD ge ge_msub(const ge& p, const ge_niels& q) {
     ge r;
     r.X = fe_mul(e, f);
     r.Y = fe_mul(g, h);
-    r.Z = fe_mul(f, g);
+    r.Z = fe_mul(g, f);  // (g first: the four products then share 2 x {e, g} and 19 x {f, h})
     r.T = fe_mul(e, h);
     return r;
 }
@@ -141,7 +141,7 @@ BBP_HD ge ge_dbl(const ge& p) {
     ge r;
     r.X = fe_mul(e, f);
     r.Y = fe_mul(g, h);
-    r.Z = fe_mul(f, g);
+    r.Z = fe_mul(g, f);  // (g first: the four products then share 2 x {e, g} and 19 x {f, h})
     r.T = fe_mul(e, h);
     return r;
 }
@@ -185,7 +185,7 @@ __device__ __forceinline__ ge ge_madd_row(const ge& p, const row_regs& q, bool n
     ge r;
     r.X = fe_mul(e, f);
     r.Y = fe_mul(g, h);
-    r.Z = fe_mul(f, g);
+    r.Z = fe_mul(g, f);  // (g first: the four products then share 2 x {e, g} and 19 x {f, h})
     r.T = fe_mul(e, h);
     return r;
 }

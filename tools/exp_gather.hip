@@ -47,7 +47,7 @@ __device__ __forceinline__ ge ge_madd_row(const ge& p, const row_regs& q, bool n
     ge r;
     r.X = fe_mul(e, f);
     r.Y = fe_mul(g, h);
-    r.Z = fe_mul(f, g);
+    r.Z = fe_mul(g, f);  // (g first: the four products then share 2 x {e, g} and 19 x {f, h})
     r.T = fe_mul(e, h);
     return r;
 }

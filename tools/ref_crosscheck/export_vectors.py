@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "..", ".."))
 from tests import uds_client as uc
 G = os.path.join(HERE, "..", "..", "tests", "golden")
-lines, expected, frames = [], [], []
+lines, expected, frames, traces = [], [], [], []
 
 
 def emit(name, c, record, score, verdict):
@@ -33,6 +33,11 @@ for fn, key in (("proofs_full.json", "full"), ("proofs_noncanonical.json", "nonc
             verify_body = uc.parse(uc.verify_request(blob, bytes.fromhex(c["q"]), bytes.fromhex(c["z_img"]), bytes.fromhex(c["seed"]), pub))[0][1:]
             frames.append(" ".join(["wire", c["name"], str(n), str(c["toggle"])] + [c[k] for k in ["d", "k", "y", "y_inv", "q", "z_img", "seed"]] +
                                    c["pub_list"] + [c["record"], prove_body.hex(), blob.hex(), verify_body.hex(), uc.tlv(blob).hex()]))
+            # `trace`: inputs + the injected entropy + the record + this repository's Fiat-Shamir challenges in transcript order
+            t = c.get("trace") or {}
+            chal = [t.get(k, "") for k in ("y", "z", "u", "x", "w")] + list(t.get("u_ipp", []))
+            traces.append(" ".join(["trace", c["name"], str(n), str(c["toggle"])] + [c[k] for k in ["d", "k", "y", "y_inv", "q", "z_img", "seed"]] + c["pub_list"] +
+                                   [c["entropy"], c["record"]] + [x for x in chal if x]))
         bad = bytearray(bytes.fromhex(c["record"]))
         bad[200] ^= 1
         emit(c["name"] + "_flipped_bit", c, bytes(bad).hex(), c["q"], "reject")
@@ -43,4 +48,5 @@ for fn, key in (("proofs_full.json", "full"), ("proofs_noncanonical.json", "nonc
 open(os.path.join(HERE, "vectors.txt"), "w").write("\n".join(lines) + "\n")
 open(os.path.join(HERE, "expected.txt"), "w").write("\n".join(expected) + "\n")
 open(os.path.join(HERE, "frames.txt"), "w").write("\n".join(frames) + "\n")
-print("wrote %d vectors, %d wire cases" % (len(lines), len(frames)))
+open(os.path.join(HERE, "trace.txt"), "w").write("\n".join(traces) + "\n")
+print("wrote %d vectors, %d wire cases, %d prover traces" % (len(lines), len(frames), len(traces)))

@@ -8,6 +8,9 @@
 //!   bbp-ref-crosscheck layout                          -> R1CSProof::to_bytes length and first byte of a fresh proof
 //!   bbp-ref-crosscheck frames  frames.txt              -> the WIRE: the reference's own TlvWriter / TlvReader against this repository's
 //!                                                         frames (server/tlv.h, server/wire.h, tests/uds_client.py); see cmd_frames
+//!   bbp-ref-crosscheck trace   trace.txt               -> BYTE parity of the PROVER: Proof::prove under scripted entropy (needs the one-file
+//!                                                         rand patch of rand_patch/README.md) against the golden records, field by field;
+//!                                                         a mismatch names the first diverging transcript step; see cmd_trace
 //!
 //! Line format (what tools/ref_crosscheck/export_vectors.py writes and check_reference_made.py reads), all hex, space separated:
 //!   name N toggle record score z_img seed pub_0 .. pub_{N-1} [d k y y_inv]
@@ -257,6 +260,136 @@ fn cmd_frames(path: &str) {
     }
 }
 
+/// The compact R1CSProof layout this repository assumes: version byte, 11 points, 3 scalars, then
+/// the inner-product proof: 2 k points L_1 R_1 .. L_k R_k and the scalars a, b (k = 11 for the 2048-multiplier circuit).  Field names
+/// are paired with the transcript step that must already agree for the field to agree: the FIRST differing field names the step.
+fn proof_fields(k: usize) -> Vec<(String, usize, &'static str)> {
+    let mut f: Vec<(String, usize, &'static str)> = vec![("version byte".into(), 1, "R1CSProof::to_bytes layout (phase marker)")];
+    for (n, why) in [
+        ("A_I1", "witness assignment a_L / a_R, generators G / H / B_blinding, blinding i~ (first draw of the TranscriptRng)"),
+        ("A_O1", "a_O, blinding o~"),
+        ("S1", "the TranscriptRng itself: witness rekeying order, 64-byte draws s_L / s_R in multiplier order, blinding s~"),
+        ("A_I2", "identity in a one-phase proof"),
+        ("A_O2", "identity in a one-phase proof"),
+        ("S2", "identity in a one-phase proof"),
+        ("T_1", "challenges y, z (labels, what was absorbed before them: V commitments, m, A_I1 A_O1 S1 [A_I2 A_O2 S2]), flattened constraint weights wL wR wO wV, polynomial coefficient t_1, its blinding (rng draw order)"),
+        ("T_3", "t_3 and its blinding"),
+        ("T_4", "t_4 and its blinding"),
+        ("T_5", "t_5 and its blinding"),
+        ("T_6", "t_6 and its blinding"),
+    ]
+    .iter()
+    {
+        f.push(((*n).into(), 32, *why));
+    }
+    f.push(("t_x".into(), 32, "challenges u (phase separator) and x, evaluation t(x)"));
+    f.push(("t_x_blinding".into(), 32, "blinding polynomial at x: the wV . v_blinding term and the T_i blindings"));
+    f.push(("e_blinding".into(), 32, "x (i~ + x o~ + x^2 s~) combination"));
+    for j in 1..=k {
+        f.push((format!("L_{}", j), 32, if j == 1 { "challenge w (Q = w B), the y^-i factors on H, l(x) / r(x) vectors, padding of the multipliers to 2048" } else { "IPA challenge u_(j-1) (label, L and R absorbed in this order) and the vector folding" }));
+        f.push((format!("R_{}", j), 32, "same round: the other halves"));
+    }
+    f.push(("a".into(), 32, "last IPA challenge and the final fold"));
+    f.push(("b".into(), 32, "last IPA challenge and the final fold"));
+    f
+}
+
+/// `trace`: the PROVER, byte for byte.  Needs `rand::thread_rng()` to hand out scripted bytes (rand_patch/README.md: one function of
+/// rand 0.6.5 edited, wired in with a [patch.crates-io] entry; nothing of the reference or of bulletproofs is touched).  Input lines
+/// (export_vectors.py, from tests/golden/proofs_full.json):
+///   trace NAME N TOGGLE  d k y y_inv q z_img seed  pub_0..pub_{N-1}  ENTROPY  RECORD  y z u x w u_1..u_k
+/// ENTROPY is this repository's injected entropy: 4 + N blinding scalars (32 bytes each) then the 32-byte seed of the TranscriptRng.
+/// The reference draws 64 bytes per blinding and reduces them (Scalar::random, proof.rs:53-64), then 32 bytes inside
+/// Prover::prove (TranscriptRngBuilder::finalize): the script fed to the patched thread_rng is  blinding || 32 zero bytes  per
+/// blinding (a canonical scalar reduces to itself), then the seed.  With that, Proof::prove is deterministic and its record must
+/// equal RECORD.  On a mismatch the fields are compared in transcript order and the first differing one is reported with the step it
+/// depends on and this repository's challenge values up to that step (the golden trace), so that the three implementations are
+/// corrected in ONE place each: oracle/ref_py/r1cs.py, oracle/c/bbp_oracle.c, dusk_blindbidproof_amd/csrc/prover.hip (+ keccak.h for
+/// the rng, setup.hip for the generators).
+fn cmd_trace(path: &str) {
+    let mut failed = 0;
+    for line in fs::read_to_string(path).expect("trace file").lines() {
+        let f: Vec<&str> = line.split_whitespace().collect();
+        if f.len() < 14 || f[0] != "trace" {
+            continue;
+        }
+        let (name, n, toggle) = (f[1], f[2].parse::<usize>().unwrap(), f[3].parse::<u64>().unwrap());
+        let sc = |i: usize| Scalar::from_canonical_bytes(arr32(&unhex(f[i]))).expect("canonical scalar in a golden vector");
+        let (d, kk, y, y_inv, q, z_img, seed) = (sc(4), sc(5), sc(6), sc(7), sc(8), sc(9), sc(10));
+        let bids: Vec<Bid> = (0..n).map(|i| Bid { x: Scalar::from_bits(arr32(&unhex(f[11 + i]))) }).collect();
+        let entropy = unhex(f[11 + n]);
+        let golden = unhex(f[12 + n]);
+        assert_eq!(entropy.len(), 32 * (4 + n) + 32, "entropy = (4 + N) blindings || rng seed");
+        let mut script = Vec::new();
+        for b in 0..4 + n {
+            script.extend_from_slice(&entropy[32 * b..32 * b + 32]);
+            script.extend_from_slice(&[0u8; 32]);
+        }
+        script.extend_from_slice(&entropy[32 * (4 + n)..]);
+        // read by the patched rand::thread_rng (rand_patch/README.md); every call of THIS process consumes from the front
+        env::set_var("BBP_SCRIPTED_ENTROPY", hex(&script));
+        env::set_var("BBP_SCRIPTED_ENTROPY_RESET", name);
+        let proof = Proof::prove(d, kk, y, y_inv, q, z_img, seed, bids, toggle).expect("prove");
+        let mut record = proof.proof.to_bytes();
+        for p in proof.commitments.iter().chain(proof.t_c.iter()) {
+            record.extend_from_slice(p.as_bytes());
+        }
+        if env::var("BBP_SCRIPTED_ENTROPY_USED").is_err() {
+            eprintln!("{}: rand::thread_rng is NOT the scripted one (BBP_SCRIPTED_ENTROPY_USED unset): apply rand_patch/README.md first", name);
+            std::process::exit(2);
+        }
+        if record == golden {
+            println!("{} IDENTICAL ({} bytes): prover parity pinned for N = {}", name, record.len(), n);
+            continue;
+        }
+        failed += 1;
+        println!("{} DIFFERENT (reference {} bytes, golden {} bytes)", name, record.len(), golden.len());
+        let plen_ref = record.len() - 32 * (4 + n);
+        let plen_gold = golden.len() - 32 * (4 + n);
+        // commitments first: they are absorbed before anything else (V_i = v_i B + blinding_i B_blinding)
+        let mut first: Option<String> = None;
+        for i in 0..4 + n {
+            let (a, b) = (&record[plen_ref + 32 * i..plen_ref + 32 * i + 32], &golden[plen_gold + 32 * i..plen_gold + 32 * i + 32]);
+            if a != b && first.is_none() {
+                first = Some(format!("commitment V_{} (Pedersen generators B / B_blinding, the blinding script, or the committed value)", i));
+            }
+        }
+        if plen_ref != plen_gold {
+            println!("    proof part: reference {} bytes, this repository {} bytes: R1CSProof::to_bytes layout (SURVEY.md A.8)", plen_ref, plen_gold);
+        }
+        let k = 11;
+        let mut off = 0;
+        for (fname, len, why) in proof_fields(k) {
+            if off + len > plen_ref.min(plen_gold) {
+                break;
+            }
+            let same = record[off..off + len] == golden[off..off + len];
+            println!("    {:<14} {}", fname, if same { "same".to_string() } else { format!("DIFFERENT  reference {}  golden {}", hex(&record[off..off + len]), hex(&golden[off..off + len])) });
+            if !same && first.is_none() {
+                first = Some(format!("{}: {}", fname, why));
+            }
+            off += len;
+        }
+        println!("    FIRST DIVERGENCE: {}", first.unwrap_or_else(|| "none inside the common prefix: trailing bytes differ".into()));
+        let names = ["y", "z", "u", "x", "w"];
+        println!("    this repository's challenges for this vector (golden trace), in transcript order:");
+        for (i, nm) in names.iter().enumerate() {
+            if let Some(v) = f.get(13 + n + i) {
+                println!("      {:<4} {}", nm, v);
+            }
+        }
+        for j in 0..k {
+            if let Some(v) = f.get(13 + n + names.len() + j) {
+                println!("      u_{:<2} {}", j + 1, v);
+            }
+        }
+    }
+    if failed != 0 {
+        eprintln!("{} vector(s) differ: README.md 'trace' lists the one function per implementation to edit for each step", failed);
+        std::process::exit(1);
+    }
+}
+
 fn main() {
     let a: Vec<String> = env::args().collect();
     match a.get(1).map(|s| s.as_str()) {
@@ -264,6 +397,7 @@ fn main() {
         Some("make") if a.len() == 5 => cmd_make(a[2].parse().unwrap(), a[3].parse().unwrap(), &a[4]),
         Some("layout") => cmd_layout(),
         Some("frames") if a.len() == 3 => cmd_frames(&a[2]),
-        _ => eprintln!("usage: bbp-ref-crosscheck verify VECTORS | make K N OUT | layout | frames FRAMES"),
+        Some("trace") if a.len() == 3 => cmd_trace(&a[2]),
+        _ => eprintln!("usage: bbp-ref-crosscheck verify VECTORS | make K N OUT | layout | frames FRAMES | trace TRACE"),
     }
 }
