@@ -7,7 +7,7 @@
 # initialised the GPU -- the exec hop this pool forbids).  Writes gpurun_out/prof/<TAG>_*.csv|json and UPDATES profiles/traffic.json
 # in the snapshot's gpurun_out/prof/ (copy what is to be judged into profiles/ afterwards).
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof
 rm -rf "$OUT"; mkdir -p "$OUT"
