@@ -348,7 +348,7 @@ class ProveWorkload(_Base):
     def cpu_baseline(self):
         lib = _oracle_lib()
         threads = host_threads()
-        sample = 2 * threads
+        sample = 4 * threads  # ~22 core-seconds of oracle work on a 16-thread box (0.34 s per proof), ~1.4 s of wall time
         ins = b"".join(self.ins[i % self.B] for i in range(sample))
         ents = b"".join(self.ents[i % self.B] for i in range(sample))
         t0 = time.perf_counter()

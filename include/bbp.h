@@ -236,7 +236,12 @@ int32_t bbp_debug_compile_circuit(uint32_t N, uint32_t* n_mul, uint32_t* n_cons)
 
 /* Diagnostics: a short text report of what the context (every member of a pool) runs on and how it is configured -- device, free
  * memory, scheduling knobs -- into buf (NUL-terminated, truncated to cap).  Conditions known to cost throughput silently are
- * reported as lines starting with "WARNING:" (today: GPU_MAX_HW_QUEUES below 8 in the environment, little free device memory). */
+ * reported as lines starting with "WARNING:" (today: GPU_MAX_HW_QUEUES below 8, or unset while HIP was already initialised when
+ * the engine was created; little free device memory).  The report also says where the hardware-queue setting came from -- bbp_init
+ * exports GPU_MAX_HW_QUEUES=16 itself when the variable is unset and the process has not initialised HIP yet -- and how much
+ * scratch the context holds in how many allocations (after bbp_reserve that count stands still).
+ * Environment, read once per process: BBP_DEBUG_DEVICE_CHECK=1 asserts before every HIP call made for a context that the calling
+ * thread's current device is the context's (first multi-GPU bring-up); BBP_TRACE_ALLOC=1 names every scratch buffer that grows. */
 int32_t bbp_describe(bbp_ctx* ctx, char* buf, uint32_t cap);
 
 /* Test hook: poisons the sorted scratch of the context's NEXT MSM launch with an out-of-range entry (what a stray write would leave).

@@ -60,6 +60,11 @@ def main():
     out = a.out or os.path.join(ROOT, "gpurun_out", "ab", tag + ".jsonl")
     os.makedirs(os.path.dirname(out), exist_ok=True)
     knobs = ["BBP_LIB_VARIANT"] if a.knob == "variant" else a.knob.split(",")
+    # native artefacts once, before the first run (every run then passes --no-build and would refuse a stale library)
+    b = subprocess.run([sys.executable, os.path.join(ROOT, "__graft_entry__.py")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if b.returncode != 0:
+        sys.stderr.write(b.stdout.decode()[-2000:])
+        return 1
     box = box_id()
     rows = []
     with open(out, "a") as f:

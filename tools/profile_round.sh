@@ -14,6 +14,8 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 python3 $REPO/__graft_entry__.py > "$OUT/build.log" 2>&1
 cp $REPO/profiles/traffic.json "$OUT/traffic.json" 2>/dev/null || echo "{}" > "$OUT/traffic.json"
 cd /tmp && export TMPDIR=/tmp
+# no bbp_reserve before the clock: its thirteen dummy prove batches would be counted into every per-launch average and into the traffic
+export BBP_BENCH_NO_RESERVE=1
 B="python3 $REPO/bench.py --no-also --no-cpu-baseline --no-build --no-exclusive"
 PMC_STEPS=2   # every counter pass runs --steps 1 --warmup 1: two steps of the workload execute
 stats() { rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$1" -o "$1" -- $B "${@:3}" > "$OUT/$2" 2> "$OUT/$1.log"; echo "$1 stats pass done"; }
