@@ -219,13 +219,15 @@ __device__ __forceinline__ i64 fe_col5v(i64 addend, i32 a0, i32 b0, i32 a1, i32 
 #undef BBP_MAD0V
 #undef BBP_MAD0
 #undef BBP_MADN
+#endif
+
 // BBP_FE_CHAIN (default; -DBBP_FE_NO_CHAIN for the separate carry pass): the carry pass threaded THROUGH the column sums.  Columns are summed in order; an even column's seed constant is its own
 // rounding bias plus the next (odd) column's bias shifted up by its 26 bits, so that its carry h >> 26 already contains that bias and can
 // be the FIRST ADDEND of the odd column's chain (free); the odd column's carry is added to the next even column with one 64-bit add.  Four
 // explicit 64-bit adds per multiplication instead of nine, and no second visit of columns 4 and 0 beyond the wrap (19 c9 into limb 0).
 // The carry order differs from fe_carry64_prebiased, so limbs may differ -- the field element does not (every output is carried).
 constexpr i64 FE_SEED_EVEN = ((i64)1 << 25) + ((i64)1 << 50);
-__device__ __forceinline__ void fe_chain_step(fe& r, i64& c, int k, i64 hk) {  // hk: column k with its seed / carry-in already inside
+BBP_HD void fe_chain_step(fe& r, i64& c, int k, i64 hk) {  // hk: column k with its seed / carry-in already inside
     if (k & 1) {
         c = hk >> 25;
         r.v[k] = (i32)((u32)hk & ((1u << 25) - 1u)) - (i32)(1u << 24);
@@ -234,13 +236,37 @@ __device__ __forceinline__ void fe_chain_step(fe& r, i64& c, int k, i64 hk) {  /
         r.v[k] = (i32)((u32)hk & ((1u << 26) - 1u)) - (i32)(1u << 25);
     }
 }
-__device__ __forceinline__ void fe_chain_wrap(fe& r, i64 c9) {  // column 9 wraps to column 0 times 19, then one small carry 0 -> 1
+BBP_HD void fe_chain_wrap(fe& r, i64 c9) {  // column 9 wraps to column 0 times 19, then one small carry 0 -> 1
     const i64 x0 = (i64)r.v[0] + 19 * c9;
     const i64 c = (x0 + ((i64)1 << 25)) >> 26;
     r.v[0] = (i32)(x0 - (c << 26));
     r.v[1] += (i32)c;
 }
-#endif
+
+// The same threaded carry pass over column sums computed in plain C: what the device path does with its assembly chains, for the
+// host (tests/host_check.cpp op 11 / 12 drives it with the product's own fe_chain_step / fe_chain_wrap: seed constants, carry order
+// and limb bounds are checked on the CPU tier; the GPU tier checks the assembly against the oracle).
+BBP_HD fe fe_mul_chain_portable(const fe& f, const fe& g) {
+    i32 g19[10], f2[10];
+    for (int i = 0; i < 10; i++) {
+        g19[i] = 19 * g.v[i];
+        f2[i] = 2 * f.v[i];
+    }
+    fe r;
+    i64 c = 0;
+    for (int k = 0; k < 10; k++) {
+        i64 hk = (k & 1) ? c : FE_SEED_EVEN + (k ? c : 0);
+        for (int i = 0; i < 10; i++) {
+            const int j = (k - i + 10) % 10;
+            const i32 a = ((i & 1) && (j & 1)) ? f2[i] : f.v[i];
+            const i32 b = (i + j >= 10) ? g19[j] : g.v[j];
+            hk += (i64)a * b;
+        }
+        fe_chain_step(r, c, k, hk);
+    }
+    fe_chain_wrap(r, c);
+    return r;
+}
 
 // term f_i g_j lands in column (i+j) mod 10, times 19 when i+j >= 10 (2^255 = 19), times 2 when i and j are both odd
 BBP_HD fe fe_mul(const fe& f, const fe& g) {

@@ -12,7 +12,7 @@ static void ld(u32* w, const uint8_t* b, int nwords) { memcpy(w, b, 4 * nwords);
 
 extern "C" {
 
-// op: 0 add, 1 sub, 2 mul, 3 sq, 4 invert, 5 canon(a), 6 neg, 7 pow22523, 8 mul_small(a, b[0])
+// op: 0 add, 1 sub, 2 mul, 3 sq, 4 invert, 5 canon(a), 6 neg, 7 pow22523, 8 mul_small(a, b[0]), 9 sq2, 10 growth, 11 / 12 threaded-carry multiply
 void hc_fe_op(int op, const uint8_t* a32, const uint8_t* b32, uint8_t* out32) {
     u32 wa[8], wb[8];
     ld(wa, a32, 8);
@@ -34,6 +34,20 @@ void hc_fe_op(int op, const uint8_t* a32, const uint8_t* b32, uint8_t* out32) {
             fe s = fe_add(fe_add(m1, m1), m2), d = fe_sub(fe_sub(m3, m2), m1);
             r = fe_mul(s, d);
             r = fe_sq(fe_sub(fe_add(r, m1), m3));
+            break;
+        }
+        case 11: r = fe_mul_chain_portable(a, b); break;  // the device path's threaded carry pass (field.h), column sums in plain C
+        case 12: {  // the same on maximally loaded operands (three-term sums, as the point formulas feed them), limb bounds checked
+            fe m1 = fe_mul_chain_portable(a, b), m2 = fe_mul_chain_portable(b, b), m3 = fe_mul_chain_portable(b, fe_mul_chain_portable(a, a));
+            fe s = fe_add(fe_add(m1, m1), m2), d = fe_sub(fe_sub(m3, m2), m1);
+            r = fe_mul_chain_portable(s, d);
+            for (int i = 0; i < 10; i++) {  // carried: |h_even| <= 2^25, |h_odd| <= 2^24 (+ the one small carry into limb 1)
+                const i32 bound = (i & 1) ? (1 << 24) : (1 << 25);
+                const i32 v = r.v[i] < 0 ? -r.v[i] : r.v[i];
+                if (v > bound + (i == 1 ? (1 << 17) : 0)) r = fe_zero();  // reported as a wrong value
+            }
+            fe t = fe_sub(fe_add(r, m1), m3);
+            r = fe_mul_chain_portable(t, t);
             break;
         }
         default: r = fe_zero(); break;

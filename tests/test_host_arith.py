@@ -46,6 +46,10 @@ def test_field_ops(lib):
             m1, m2, m3 = a * b % P, b * b % P, b * a * a % P
             r = (2 * m1 + m2) * (m3 - m2 - m1) % P
             assert fe_op(10, a0, b0) == pow(r + m1 - m3, 2, P)
+            # round 4: the device path threads the carries through the column sums (field.h fe_chain_step / fe_chain_wrap, seed 2^25 +
+            # 2^50 on even columns); the same functions over plain-C column sums must give the same field element, limbs carried
+            assert fe_op(11, a0, b0) == (a * b) % P
+            assert fe_op(12, a0, b0) == pow(r + m1 - m3, 2, P)
         assert fe_op(3, a0) == a * a % P
         assert fe_op(9, a0) == 2 * a * a % P
         assert fe_op(5, a0) == a % P
