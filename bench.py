@@ -320,6 +320,10 @@ def main():
         wl.check()  # parity of the warmed-up output against the oracle on a sample (not timed)
 
     alu_peak = None if STUB else max(ctx.ubench(3, 8192, 2000) for _ in range(2))  # register-resident ge_madd chains: the integer-ALU ceiling
+    # ... and the same loop with a table operand the compiler cannot see through (kind 5: the 19 x limb products of a freshly gathered
+    # row cannot be hoisted): the ceiling the accumulate loop can actually be held against.  Both run the engine's own field
+    # multiplication, so they move with it (round 4: +12 %) -- read `frac` / `dominant_ms_per_step` for progress, `alu_frac` for distance.
+    alu_peak_fresh = None if STUB else max(ctx.ubench(5, 8192, 2000) for _ in range(2))
     dt, timings = timed(wl, ctx, torch, dist, world, args.steps, stream)
     tmax = torch.tensor([dt], device=red_dev, dtype=torch.float64)
     per_rank_s = [dt]
@@ -404,7 +408,11 @@ def main():
                                "note": "each rank's own units/s over its own clock between the barriers; `value` = all units / the slowest rank's time"}
         if not STUB:
             out["roofline"] = roofline(wl, timings, args.steps, alu_peak, dt)
+            if alu_peak_fresh:
+                out["roofline"]["alu"]["peak_fresh_row"] = alu_peak_fresh
             if exclusive:
+                if alu_peak_fresh and exclusive.get("alu_frac"):
+                    exclusive["alu_frac_fresh_row"] = exclusive["alu_frac"] * alu_peak / alu_peak_fresh
                 out["roofline"]["exclusive"] = exclusive
         out.update(wl.extra_report(timings))
         if gather_info:
