@@ -339,7 +339,7 @@ extern "C" int32_t bbp_pool_init(const int32_t* devices, uint32_t n_devices, bbp
         const char* qu = getenv("BBP_BATCH_QUIET_US");
         c->set_quiet(qu ? (uint32_t)atoi(qu) : 300u, qc ? (uint32_t)atoi(qc) : 8000u);
         const char* hm = getenv("BBP_BATCH_HOLD_MARGIN_US");
-        c->set_hold(hm ? atoi(hm) : 4000, 40000u, 48.0);
+        c->set_hold(hm ? atoi(hm) : 4000, 40000u, 48.0, !getenv("BBP_BATCH_HOLD_FIXED"));
         return BBP_OK;
     } catch (const std::exception& e) {
         if (pool) pool->err = std::string("bbp_pool_init: ") + e.what();

@@ -206,7 +206,7 @@ static int32_t init_body(int32_t device, bbp_ctx** out) {
         const char* qu = getenv("BBP_BATCH_QUIET_US");
         static_cast<Combiner*>(ctx->combiner)->set_quiet(qu ? (uint32_t)atoi(qu) : 300u, qc ? (uint32_t)atoi(qc) : 8000u);
         const char* hm = getenv("BBP_BATCH_HOLD_MARGIN_US");  // -1 = off
-        static_cast<Combiner*>(ctx->combiner)->set_hold(hm ? atoi(hm) : 4000, 40000u, 48.0);  // ~40 ms opening stage, ~48 us per proof
+        static_cast<Combiner*>(ctx->combiner)->set_hold(hm ? atoi(hm) : 4000, 40000u, 48.0, !getenv("BBP_BATCH_HOLD_FIXED"));  // ~40 ms opening stage, ~48 us per proof
     }
     if (getenv("BBP_TRACE_ALLOC")) {  // the field map that goes with dev_reserve's "[bbp alloc] ... context offset" lines
 #define BBP_OFF(f) (size_t)(reinterpret_cast<const char*>(&ctx->f) - reinterpret_cast<const char*>(ctx))

@@ -38,11 +38,12 @@ void Combiner::set_quiet(uint32_t quiet_us, uint32_t cap_us) {
     quiet_cap_us_ = cap_us;
 }
 
-void Combiner::set_hold(int32_t margin_us, uint32_t open_us, double per_proof_us) {
+void Combiner::set_hold(int32_t margin_us, uint32_t open_us, double per_proof_us, bool adapt) {
     std::lock_guard<std::mutex> lk(mu_);
     hold_margin_us_ = margin_us;
     open_us_ = open_us;
-    per_proof_us_ = per_proof_us;
+    per_proof_us_ = per_proof_us0_ = per_proof_us;
+    adapt_ = adapt;
 }
 
 void Combiner::set_small_stagger(uint32_t small_batch, uint32_t us) {
@@ -301,12 +302,24 @@ void Combiner::thread_main(int kind) {
         lk.lock();
         if (log_) {  // BBP_BATCH_LOG: start (ms since the combiner was made), duration, kind, target, size, prove batches already in flight, queue left behind
             const auto t_end = std::chrono::steady_clock::now();
-            fprintf(log_, "%.2f %.2f %s %zu %zu %d %zu\n", std::chrono::duration<double, std::milli>(t_batch - t0_).count(),
-                    std::chrono::duration<double, std::milli>(t_end - t_batch).count(), proving ? "prove" : "verify", ti, batch.size(), inflight_before, q_left);
+            fprintf(log_, "%.2f %.2f %s %zu %zu %d %zu %.1f\n", std::chrono::duration<double, std::milli>(t_batch - t0_).count(),
+                    std::chrono::duration<double, std::milli>(t_end - t_batch).count(), proving ? "prove" : "verify", ti, batch.size(), inflight_before, q_left,
+                    per_proof_us_);  // (last column: the pacing estimate, microseconds per proof, as it stood when this batch ended)
         }
         if (proving) {
+            const auto t_end = std::chrono::steady_clock::now();
+            if (adapt_ && inflight_before > 0 && batch.size() >= 256) {
+                // what a proof of this batch cost once the device was its own: its MSM stage could start when its opening stage was over
+                // AND the batch ahead of it had ended (that batch's end is still in last_done: it ended first)
+                const auto heavy_from = std::max(targets_[ti].last_done, t_batch + std::chrono::microseconds(open_us_));
+                const double us = std::chrono::duration<double, std::micro>(t_end - heavy_from).count() / (double)batch.size();
+                if (us > 0.5 * per_proof_us0_ && us < 1.5 * per_proof_us0_) {
+                    per_proof_us_ = 0.75 * per_proof_us_ + 0.25 * us;
+                    per_proof_us_ = std::min(1.25 * per_proof_us0_, std::max(0.6 * per_proof_us0_, per_proof_us_));
+                }
+            }
             targets_[ti].prove_inflight--;
-            targets_[ti].last_done = std::chrono::steady_clock::now();
+            targets_[ti].last_done = t_end;
             targets_[ti].last_done_size = batch.size();
         }
         targets_[ti].running[kind]--;

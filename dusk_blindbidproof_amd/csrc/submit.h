@@ -89,7 +89,11 @@ class Combiner {
     void set_quiet(uint32_t quiet_us, uint32_t cap_us);
     // Behind a prove batch in flight the next one leaves no earlier than (expected end of that batch) - open_us - margin_us, where a
     // batch of B proofs is expected to take open_us (opening stage) + per_proof_us * B once the device is its own.  margin_us < 0 = off.
-    void set_hold(int32_t margin_us, uint32_t open_us, double per_proof_us);
+    // adapt: per_proof_us is then only the starting value -- the combiner measures what a proof of a pipelined batch really costs
+    // (end of the batch minus the later of the previous batch's end and this batch's opening stage, per proof; running average,
+    // kept within -40 % / +25 % of the starting value) and paces with that: a constant calibrated for one engine build paces a
+    // faster one at the old rate (round 4: the engine got 6 % faster and the socket did not, until this).
+    void set_hold(int32_t margin_us, uint32_t open_us, double per_proof_us, bool adapt = false);
     // A prove burst that finds its device idle and holds at least 2 n requests is cut in two (each half >= n): 0 = never.
     void set_split_min(uint32_t n);
     void stats(uint64_t* n_calls, uint64_t* n_requests, uint32_t* max_seen);
@@ -135,7 +139,8 @@ class Combiner {
     int32_t hold_margin_us_ = -1;
     bool lopsided_ = true;  // set_lopsided_wait: a few requests behind one large batch wait for its callers (closed-loop clients)
     uint32_t small_batch_ = 0, small_stagger_us_ = 0xffffffffu;
-    double per_proof_us_ = 48.0;
+    double per_proof_us_ = 48.0, per_proof_us0_ = 48.0;
+    bool adapt_ = false;
     uint64_t n_calls_ = 0, n_requests_ = 0;
     uint32_t max_seen_ = 0;
     FILE* log_ = nullptr;  // BBP_BATCH_LOG=path: one line per batch (tools/batch_log.py)
