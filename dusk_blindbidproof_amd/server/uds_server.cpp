@@ -735,6 +735,13 @@ int main(int argc, char** argv) {
         fflush(stderr);
         _exit(1);  // static destructors / HIP teardown under running GPU work can hang or abort
     }
+    if (g_fatal.load()) {
+        // the handle reported a device failure: tearing HIP state down on a device in an unknown condition can hang; the process is
+        // about to be replaced anyway
+        logf(0, "leaving with status %d without tearing the engine down (device failure)", EXIT_ENGINE_DEAD);
+        fflush(stderr);
+        _exit(EXIT_ENGINE_DEAD);
+    }
     g_eng.free_(g_eng.ctx);
-    return g_fatal.load() ? EXIT_ENGINE_DEAD : 0;
+    return 0;
 }

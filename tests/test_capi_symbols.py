@@ -58,6 +58,30 @@ def test_no_verdict_changing_knobs_in_the_product(bbp):
     assert b"BBP_SLICES" in blob  # (the scheduling knobs are there: the scan does see getenv strings)
 
 
+def test_init_exports_the_hardware_queue_setting_before_touching_hip(bbp):
+    """Round 4: bbp_init owns GPU_MAX_HW_QUEUES.  Without a GPU the call fails (status 5, no CPU path) -- but the variable must have
+    been exported BEFORE the first HIP call, which is what makes it effective on a GPU box; a value the caller set is left alone.
+    Fresh processes that load only the library (the GPU tier checks the three cases on hardware through bbp_describe)."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes, sys\n"
+        "L = ctypes.CDLL(sys.argv[1])\n"
+        "h = ctypes.c_void_p()\n"
+        "L.bbp_init.argtypes = [ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)]\n"
+        "rc = L.bbp_init(0, ctypes.byref(h))\n"
+        "libc = ctypes.CDLL(None)\n"
+        "libc.getenv.restype = ctypes.c_char_p\n"
+        "print('RC', rc, 'ENV', libc.getenv(b'GPU_MAX_HW_QUEUES'))\n")
+    for preset, expect in ((None, b"16"), ("8", b"8")):
+        env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+        if preset:
+            env["GPU_MAX_HW_QUEUES"] = preset
+        p = subprocess.run([sys.executable, "-c", code, bbp.lib_path], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-1500:]
+        assert ("ENV %r" % expect) in p.stdout, (preset, p.stdout, p.stderr[-300:])
+
+
 def test_circuit_synthesis_sizes_and_statuses(bbp):
     """Host-only synthesis through the C ABI (no device): n_mul = 1442 + 3N, n_cons = 2 n_mul + 3 + 3N; the states
     the reference panics on / rejects come back as statuses."""
