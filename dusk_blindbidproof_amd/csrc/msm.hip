@@ -176,11 +176,12 @@ template <> struct msm_geom<1> { static constexpr int K = FOLD_K, NAF = FOLD_NAF
 template <int MODE>
 __global__ __launch_bounds__(SORT_T) void k_msm_sort(const u32* __restrict__ scal_a, const u32* __restrict__ aux, u32 n_total, u32 n_idx_sets,
                                                       u32 n_sub, u32 split, u32* __restrict__ sorted_all, u32* __restrict__ cursor_all,
-                                                      const u32* __restrict__ msm_map, const u32* __restrict__ n_active) {
+                                                      const u32* __restrict__ msm_map, const u32* __restrict__ n_active, u32* __restrict__ ticket) {
     constexpr int K = msm_geom<MODE>::K, NAF = msm_geom<MODE>::NAF, W = msm_geom<MODE>::W, G = K / SORT_T;
     __shared__ u32 cursor[K + 1];  // histogram, then bucket start offsets, then (after the scatter) bucket end offsets
     __shared__ u32 part[SORT_T];
     const int tid = threadIdx.x;
+    if (ticket && blockIdx.x == 0 && tid == 0) *ticket = 0;  // work counter of the accumulate launch that follows on this stream (BBP_ACC_PERSIST)
     // device-sized launches (MODE 0, split = 1): the grid covers the largest possible number of MSMs, *n_active of them exist
     // (the whole workgroup leaves together), and MSM j takes its scalars from row msm_map[j] of the scalar array
     if (n_active && blockIdx.x >= *n_active) return;
@@ -283,13 +284,14 @@ constexpr u32 SORT_WIDE_FROM = 3000;
 template <int MODE>
 __global__ __launch_bounds__(SORT_T) void k_msm_sort_staged(const u32* __restrict__ scal_a, const u32* __restrict__ aux, u32 n_total, u32 n_idx_sets,
                                                              u32 n_sub, u32 split, u32* __restrict__ sorted_all, u32* __restrict__ cursor_all,
-                                                             const u32* __restrict__ msm_map, const u32* __restrict__ n_active, u32 CAP) {
+                                                             const u32* __restrict__ msm_map, const u32* __restrict__ n_active, u32 CAP, u32* __restrict__ ticket) {
     constexpr int K = msm_geom<MODE>::K, NAF = msm_geom<MODE>::NAF, W = msm_geom<MODE>::W, G = K / SORT_T;
     extern __shared__ u32 stage[];  // [CAP] entries: the image of one window
     __shared__ u32 start[K + 2];  // start[k] = position of bucket k's first entry (k = 1..K), start[K + 1] = number of entries
     __shared__ u32 fill[K + 1];   // histogram, then entries placed so far per bucket
     __shared__ u32 part[SORT_T];
     const int tid = threadIdx.x;
+    if (ticket && blockIdx.x == 0 && tid == 0) *ticket = 0;
     if (n_active && blockIdx.x >= *n_active) return;
     const size_t work = blockIdx.x, msm = work / split;
     const u32 i0 = (u32)(work % split) * n_sub;
@@ -412,12 +414,28 @@ static_assert(ACC_T % ACC_WG == 0 && ACC_WG % 64 == 0, "accumulate workgroup geo
 template <int MODE>
 __global__ __launch_bounds__(ACC_WG) __attribute__((amdgpu_waves_per_eu(BBP_MSM_WAVES, BBP_MSM_WAVES_MAX)))
 void k_msm_acc(const niels_row* __restrict__ ptable, const u32* __restrict__ sorted_all, const u32* __restrict__ cursor_all, u32 n /* sorted stride */,
-               ge* __restrict__ bsum_all, ge* __restrict__ psum_all, ge* __restrict__ out, const u32* __restrict__ n_active, u32* __restrict__ fault) {
+               ge* __restrict__ bsum_all, ge* __restrict__ psum_all, ge* __restrict__ out, const u32* __restrict__ n_active, u32* __restrict__ fault,
+               u32 n_work, u32* __restrict__ ticket) {
     constexpr int K = msm_geom<MODE>::K, W = msm_geom<MODE>::W, G = K / MSM_T;  // (G: unused here since the fold moved out)
     __shared__ u32 cursor[K + 1];
+#ifdef BBP_ACC_PERSIST
+    // experiment: at most 2 x CUs workgroups stay resident and draw MSMs from a ticket counter (zeroed by the sort kernel that runs
+    // before this launch on the same stream) until none is left: no workgroup dispatch between the MSMs of a launch.  Every wave
+    // of a workgroup sees the same ticket (LDS, behind a barrier), so the exit is uniform.
+    static_assert(ACC_WGS == 1, "the persistent form draws whole MSMs");
+    __shared__ u32 s_ticket;
+  for (;;) {
+    __syncthreads();  // the previous MSM's cursor[] is no longer read by any wave
+    if (threadIdx.x == 0) s_ticket = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const size_t msm = s_ticket;
+    if (msm >= n_work || (n_active && msm >= *n_active)) return;
+    const int tid = (int)threadIdx.x;
+#else
     const size_t msm = blockIdx.x / ACC_WGS;
     const int tid = (int)(blockIdx.x % ACC_WGS) * ACC_WG + (int)threadIdx.x;  // chunk index within the MSM
     if (n_active && msm >= *n_active) return;  // device-sized launch (see k_msm_sort)
+#endif
     const u32* sorted = sorted_all + msm * (size_t)n * W;
 #ifdef BBP_MSM_PRIO
     __builtin_amdgcn_s_setprio(BBP_MSM_PRIO);
@@ -537,7 +555,9 @@ void k_msm_acc(const niels_row* __restrict__ ptable, const u32* __restrict__ sor
     __threadfence_block();
     __syncthreads();
     MSM_PROF_MARK(3);
-
+#ifdef BBP_ACC_PERSIST
+  }
+#endif
 }
 
 // The cold half of an MSM as a kernel of its own: chunk-leading partial sums into their buckets (P), running-sum fold over each
@@ -881,6 +901,7 @@ static u32 msm_split(u32 n_msm, u32 n_terms) {
 struct MsmScratch {
     u32 *sorted, *cursor;
     ge *bsum, *psum, *tmp;  // tmp: partial results of split MSMs
+    u32* ticket;            // (BBP_ACC_PERSIST) the accumulate launch's work counter: zeroed by the sort kernel ahead of it
     size_t bytes;
 };
 static MsmScratch msm_scratch_layout(void* base, size_t n_msm, size_t n_terms, size_t W, size_t K, size_t out_items = 1) {
@@ -896,7 +917,9 @@ static MsmScratch msm_scratch_layout(void* base, size_t n_msm, size_t n_terms, s
     m.psum = reinterpret_cast<ge*>(static_cast<u8*>(base) + o);
     o += n_msm * ACC_T * sizeof(ge);
     m.tmp = reinterpret_cast<ge*>(static_cast<u8*>(base) + o);
-    o += n_msm * out_items * sizeof(ge);
+    o += up(n_msm * out_items * sizeof(ge));
+    m.ticket = reinterpret_cast<u32*>(static_cast<u8*>(base) + o);
+    o += 256;
     m.bytes = o;
     return m;
 }
@@ -905,6 +928,16 @@ size_t msm_scratch_bytes(uint32_t n_msm, uint32_t n_terms) {
     const size_t a = msm_scratch_layout(nullptr, (size_t)n_msm * split, n_sub, MSM_W, MSM_K).bytes;
     const size_t b = msm_scratch_layout(nullptr, n_msm, n_terms, MSM_W, MSM_K).bytes;  // the unsplit layout of a device-sized launch
     return a > b ? a : b;
+}
+
+// workgroups of an accumulate launch: one per MSM (x ACC_WGS); the persistent experiment keeps at most two per CU and lets them draw
+static inline u32 acc_grid(bbp_ctx*, u32 n_work) {
+#ifdef BBP_ACC_PERSIST
+    static const u32 cap = [] { const char* e = getenv("BBP_ACC_PERSIST_GRID"); return e ? (u32)atoi(e) : 512u; }();
+    return n_work < cap ? n_work : cap;
+#else
+    return n_work * ACC_WGS;
+#endif
 }
 
 int32_t fold_generators_launch(bbp_ctx* ctx, uint32_t n_proofs, const sc* g_dev, const sc* h_dev, ge* out_dev, hipStream_t stream,
@@ -925,16 +958,16 @@ int32_t fold_generators_launch(bbp_ctx* ctx, uint32_t n_proofs, const sc* g_dev,
                 ctx->sort_lds_attr1 = true;
             }
             hipLaunchKernelGGL(k_msm_sort_staged<1>, dim3((u32)n_work), dim3(SORT_T), sort_cap<1>::V * 4, stream, (const u32*)g_dev, (const u32*)h_dev, 2048u, 1u,
-                               n_sub, split, m.sorted, m.cursor, (const u32*)nullptr, (const u32*)nullptr, sort_cap<1>::V);
+                               n_sub, split, m.sorted, m.cursor, (const u32*)nullptr, (const u32*)nullptr, sort_cap<1>::V, m.ticket);
         } else
             hipLaunchKernelGGL(k_msm_sort<1>, dim3((u32)n_work), dim3(SORT_T), 0, stream, (const u32*)g_dev, (const u32*)h_dev, 2048u, 1u, n_sub, split,
-                               m.sorted, m.cursor, (const u32*)nullptr, (const u32*)nullptr);
+                               m.sorted, m.cursor, (const u32*)nullptr, (const u32*)nullptr, m.ticket);
         BBP_HIP_TRY(ctx, hipGetLastError());
     }
     {
         ScopedEvent ev(ctx, TAG_MSM, stream);
-        hipLaunchKernelGGL(k_msm_acc<1>, dim3((u32)n_work * ACC_WGS), dim3(ACC_WG), 0, stream, ctx->ptable, m.sorted, m.cursor, n_sub, m.bsum, m.psum,
-                           split > 1 ? m.tmp : out_dev, (const u32*)nullptr, ctx->health);
+        hipLaunchKernelGGL(k_msm_acc<1>, dim3(acc_grid(ctx, (u32)n_work)), dim3(ACC_WG), 0, stream, ctx->ptable, m.sorted, m.cursor, n_sub, m.bsum, m.psum,
+                           split > 1 ? m.tmp : out_dev, (const u32*)nullptr, ctx->health, (u32)n_work, m.ticket);
         BBP_HIP_TRY(ctx, hipGetLastError());
     }
     ScopedEvent evf(ctx, TAG_MSM_FOLD, stream);
@@ -990,11 +1023,11 @@ int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* sc
                 ctx->sort_lds_attr = true;
             }
             hipLaunchKernelGGL(k_msm_sort_staged<0>, dim3(n_work), dim3(SORT_T), cap * 4, stream, scalars_dev, base_idx_dev, n_terms, n_idx_sets, n_sub, split,
-                               m.sorted, m.cursor, msm_map_dev, n_active_dev, cap);
+                               m.sorted, m.cursor, msm_map_dev, n_active_dev, cap, m.ticket);
         }
         else
             hipLaunchKernelGGL(k_msm_sort<0>, dim3(n_work), dim3(SORT_T), 0, stream, scalars_dev, base_idx_dev, n_terms, n_idx_sets, n_sub, split,
-                               m.sorted, m.cursor, msm_map_dev, n_active_dev);
+                               m.sorted, m.cursor, msm_map_dev, n_active_dev, m.ticket);
         BBP_HIP_TRY(ctx, hipGetLastError());
     }
     if (ctx->debug_corrupt) {  // bbp_debug_corrupt_scratch: the next MSM launch finds an out-of-range entry in its sorted scratch
@@ -1007,8 +1040,8 @@ int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* sc
         BBP_HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->ev_vacc[ctx->vacc_seq % bbp_ctx::VACC_RING], 0));
     {
         ScopedEvent ev(ctx, TAG_MSM, stream);
-        hipLaunchKernelGGL(k_msm_acc<0>, dim3(n_work * ACC_WGS), dim3(ACC_WG), 0, stream, ctx->ptable, m.sorted, m.cursor, n_sub, m.bsum, m.psum,
-                           split > 1 ? m.tmp : out_points_dev, n_active_dev, ctx->health);
+        hipLaunchKernelGGL(k_msm_acc<0>, dim3(acc_grid(ctx, n_work)), dim3(ACC_WG), 0, stream, ctx->ptable, m.sorted, m.cursor, n_sub, m.bsum, m.psum,
+                           split > 1 ? m.tmp : out_points_dev, n_active_dev, ctx->health, n_work, m.ticket);
         BBP_HIP_TRY(ctx, hipGetLastError());
     }
     static const bool chain_after_fold = getenv("BBP_VERIFY_CHAIN_AFTER_FOLD") && atoi(getenv("BBP_VERIFY_CHAIN_AFTER_FOLD"));
