@@ -871,15 +871,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BBP_FOLD_WAV
     if (l == 0 && valid) out[msm] = v;
 }
 
-// sums the `split` partial results of every MSM: out[o] = sum_j tmp[((o / items) * split + j) * items + o % items]
-__global__ void k_msm_reduce(u32 n_out, u32 split, u32 items, const ge* __restrict__ tmp, ge* __restrict__ out) {
+// sums the `split` (<= 16) partial results of every MSM: out[o] = sum_j tmp[((o / items) * split + j) * items + o % items].
+// Sixteen lanes per output, one partial each, then a shuffle tree: four dependent additions instead of fifteen (round 4: this kernel
+// sits on the serial chain of every small call -- a single proof has 2 outputs x 16 partials per IPA round -- and one lane adding
+// fifteen points in a row was 40-60 us of it).  All lanes of a wavefront stay in the loop (the shuffles need them); lanes past n_out or
+// past `split` carry the identity.
+constexpr int REDUCE_L = 16;
+__global__ __launch_bounds__(64) void k_msm_reduce(u32 n_out, u32 split, u32 items, const ge* __restrict__ tmp, ge* __restrict__ out) {
     __builtin_amdgcn_s_setprio(3);
-    u32 o = blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= n_out) return;
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 o = t / REDUCE_L, j = t % REDUCE_L;
     const u32 msm = o / items, c = o % items;
-    ge acc = tmp[((size_t)msm * split) * items + c];
-    for (u32 j = 1; j < split; j++) acc = ge_add(acc, tmp[((size_t)msm * split + j) * items + c]);
-    out[o] = acc;
+    ge acc = ge_identity();
+    if (o < n_out && j < split) acc = tmp[((size_t)msm * split + j) * items + c];
+    for (u32 jj = j + REDUCE_L; o < n_out && jj < split; jj += REDUCE_L)  // (split <= 16 today; correct for more)
+        acc = ge_add(acc, tmp[((size_t)msm * split + jj) * items + c]);
+#pragma unroll 1
+    for (int d = REDUCE_L / 2; d >= 1; d >>= 1) {
+        const ge other = ge_shfl_down(acc, d);  // within the 16-lane group: lane j + d < 16 whenever j < d
+        if ((int)j < d) acc = ge_add(acc, other);
+    }
+    if (o < n_out && j == 0) out[o] = acc;
 }
 
 // how many workgroups an MSM of n terms is cut into when the launch has only n_msm of them (fills the GPU for small batches)
@@ -976,7 +988,7 @@ int32_t fold_generators_launch(bbp_ctx* ctx, uint32_t n_proofs, const sc* g_dev,
     BBP_HIP_TRY(ctx, hipGetLastError());
     if (split > 1) {
         const u32 n_out = (u32)n_msm * FOLD_CLS;
-        hipLaunchKernelGGL(k_msm_reduce, dim3((n_out + 63) / 64), dim3(64), lds_token(ctx), stream, n_out, split, (u32)FOLD_CLS, m.tmp, out_dev);
+        hipLaunchKernelGGL(k_msm_reduce, dim3((n_out * REDUCE_L + 63) / 64), dim3(64), lds_token(ctx), stream, n_out, split, (u32)FOLD_CLS, m.tmp, out_dev);
         BBP_HIP_TRY(ctx, hipGetLastError());
     }
     return BBP_OK;
@@ -1064,7 +1076,7 @@ int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* sc
         ctx->vacc_valid = true;
     }
     if (split > 1) {
-        hipLaunchKernelGGL(k_msm_reduce, dim3((n_msm + 63) / 64), dim3(64), lds_token(ctx), stream, n_msm, split, 1u, m.tmp, out_points_dev);
+        hipLaunchKernelGGL(k_msm_reduce, dim3((n_msm * REDUCE_L + 63) / 64), dim3(64), lds_token(ctx), stream, n_msm, split, 1u, m.tmp, out_points_dev);
         BBP_HIP_TRY(ctx, hipGetLastError());
     }
 #ifdef BBP_MSM_PROF
