@@ -49,6 +49,14 @@ constexpr int FOLD_NAF = 9;                // width-9 NAF: odd digits |d| < 256
 constexpr int FOLD_W = 29;                 // most digits per scalar
 constexpr int FOLD_M = 128;                // buckets per class
 constexpr int FOLD_K = FOLD_CLS * FOLD_M;  // 4096 composite buckets
+// Geometry of SPLIT MSMs (round 4; small batches: an MSM is cut into sub-MSMs of a few hundred terms, one workgroup each, so that a
+// launch of a handful of MSMs fills the GPU): width-9 NAF digits into 128 buckets.  A sub-MSM of 128 terms has no use for 1024 buckets
+// (2.5 entries each), and the bucket FOLD -- 38 dependent point additions over 1024 buckets on 128 lanes, 160 us -- is the longest
+// link of a single proof's heavy chain; over 128 buckets it is 21.  More additions per term (25.6 against 19.85) in an accumulate
+// launch that takes 40 us.
+constexpr int SMALL_NAF = 9;
+constexpr int SMALL_K = 1 << (SMALL_NAF - 2);  // 128
+constexpr int SMALL_W = FOLD_W;                // most digits one scalar can have at width 9
 // Extra table bases (internal, after the 4098 public ones): PAD_BASE0 + N - 1 = sum_{k = 418 + 3N}^{1023} H[k], the generators
 // that the first IPA round multiplies by ONE common scalar (the zero-padded multipliers n1 = 1442 + 3N .. 2047 contribute
 // b[i] h[i - 1024] = -y^1024 for every i): 582 table-row walks become one (prover.hip k_ipa_round, circuit_get).
@@ -125,7 +133,7 @@ struct bbp_ctx {
     // of at most rng_coop_below proofs (768; with four wavefronts per CU a 512-proof chain takes ~15 ms on 64 CUs).  BBP_RNG_COOP=0 / 1 forces, BBP_RNG_COOP_BELOW, BBP_RNG_BLOCK tune.
     int rng_coop = -1;
     int rng_coop_below = 768;
-    int rng_dpp = 1;              // cooperative chain on one wavefront per proof with DPP / permlane-swap theta (k_open_bulk8); BBP_RNG_DPP=0: the 25-lane ds_bpermute form (k_open_bulk)
+    int rng_dpp = 2;              // cooperative chain on one wavefront per proof: 2 = one half-word per lane, bit-interleaved (k_open_bulk50, keccak_wave.h); BBP_RNG_DPP=1: one word per lane, DPP / permlane-swap theta (k_open_bulk8); 0: the 25-lane ds_bpermute form (k_open_bulk)
     int rng_block = 0;            // threads per workgroup of k_open_bulk (BBP_RNG_BLOCK); 0 = by batch size: 64 (one wavefront = two proofs per reserved CU) up to 128 proofs, 128 up to 256, 256 above
     int serial_block = 64;        // threads per workgroup of those kernels: 256 = one serial wave per SIMD of the reserved CU (BBP_SERIAL_BLOCK)
     std::map<const void*, int> serial_attr;

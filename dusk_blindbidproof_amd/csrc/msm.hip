@@ -172,12 +172,13 @@ constexpr int SORT_T = BBP_SORT_T;  // lanes of the sort workgroup: the kernel i
 template <int MODE> struct msm_geom;
 template <> struct msm_geom<0> { static constexpr int K = MSM_K, NAF = MSM_NAF, W = MSM_W; };
 template <> struct msm_geom<1> { static constexpr int K = FOLD_K, NAF = FOLD_NAF, W = FOLD_W; };
+template <> struct msm_geom<2> { static constexpr int K = SMALL_K, NAF = SMALL_NAF, W = SMALL_W; };  // MODE 0's layout with fewer buckets: split MSMs
 
 template <int MODE>
 __global__ __launch_bounds__(SORT_T) void k_msm_sort(const u32* __restrict__ scal_a, const u32* __restrict__ aux, u32 n_total, u32 n_idx_sets,
                                                       u32 n_sub, u32 split, u32* __restrict__ sorted_all, u32* __restrict__ cursor_all,
                                                       const u32* __restrict__ msm_map, const u32* __restrict__ n_active, u32* __restrict__ ticket) {
-    constexpr int K = msm_geom<MODE>::K, NAF = msm_geom<MODE>::NAF, W = msm_geom<MODE>::W, G = K / SORT_T;
+    constexpr int K = msm_geom<MODE>::K, NAF = msm_geom<MODE>::NAF, W = msm_geom<MODE>::W, G = K >= SORT_T ? K / SORT_T : 1;  // buckets per lane of the scan (lanes past K idle)
     __shared__ u32 cursor[K + 1];  // histogram, then bucket start offsets, then (after the scatter) bucket end offsets
     __shared__ u32 part[SORT_T];
     const int tid = threadIdx.x;
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(SORT_T) void k_msm_sort(const u32* __restrict__ sca
     const u32* sbase;
     const u32* base_idx = nullptr;
     u32 base0 = 0;
-    if (MODE == 0) {
+    if (MODE != 1) {
         const size_t src = msm_map ? (size_t)msm_map[msm] : msm;
         sbase = scal_a + (src * (size_t)n_total + i0) * 8;
         base_idx = aux + (size_t)(msm % n_idx_sets) * n_total + i0;
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(SORT_T) void k_msm_sort(const u32* __restrict__ sca
         base0 = (side ? BBP_BASE_H0 : BBP_BASE_G0) + i0;
     }
     u32* sorted = sorted_all + work * (size_t)n_sub * W;
-    auto key = [&](u32 i, u32 mag) -> u32 { return (MODE == 0 ? 0u : ((i0 + i) & (FOLD_CLS - 1)) * FOLD_M) + ((mag + 1) >> 1); };
+    auto key = [&](u32 i, u32 mag) -> u32 { return (MODE != 1 ? 0u : ((i0 + i) & (FOLD_CLS - 1)) * FOLD_M) + ((mag + 1) >> 1); };
 
     for (int k = tid; k <= K; k += SORT_T) cursor[k] = 0;
     __syncthreads();
@@ -212,14 +213,15 @@ __global__ __launch_bounds__(SORT_T) void k_msm_sort(const u32* __restrict__ sca
         const uint4* sp = reinterpret_cast<const uint4*>(sbase + (size_t)i * 8);
         uint4 lo = sp[0], hi = sp[1];
         const u32 s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        if (MODE == 0 && base_idx[i] == MSM_SKIP_BASE) continue;  // this scalar rides on another term's merged base
+        if (MODE != 1 && base_idx[i] == MSM_SKIP_BASE) continue;  // this scalar rides on another term's merged base
         sc_for_each_naf_digit<NAF>(s, [&](u32, u32 mag, u32) { atomicAdd(&cursor[key(i, mag)], 1u); });
     }
     __syncthreads();
     // B. offsets (in place: count -> exclusive prefix)
     {
         u32 local = 0;
-        for (int r = 1; r <= G; r++) local += cursor[tid * G + r];
+        for (int r = 1; r <= G; r++)
+            if (tid * G + r <= K) local += cursor[tid * G + r];
         // block-wide exclusive scan of `local`: inclusive scan inside each wavefront by shuffles, wave totals through LDS
         // (a single lane looping over 1024 partial sums used to cost a fifth of this kernel)
         const int lane = tid & 63, wave = tid >> 6;
@@ -244,6 +246,7 @@ __global__ __launch_bounds__(SORT_T) void k_msm_sort(const u32* __restrict__ sca
         __syncthreads();
         u32 base = part[wave] + incl - local;
         for (int r = 1; r <= G; r++) {
+            if (tid * G + r > K) break;
             const u32 c = cursor[tid * G + r];
             cursor[tid * G + r] = base;
             base += c;
@@ -255,8 +258,8 @@ __global__ __launch_bounds__(SORT_T) void k_msm_sort(const u32* __restrict__ sca
         const uint4* sp = reinterpret_cast<const uint4*>(sbase + (size_t)i * 8);
         uint4 lo = sp[0], hi = sp[1];
         const u32 s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        if (MODE == 0 && base_idx[i] == MSM_SKIP_BASE) continue;
-        const u32 tb = (MODE == 0 ? base_idx[i] : base0 + i) * MSM_POS;
+        if (MODE != 1 && base_idx[i] == MSM_SKIP_BASE) continue;
+        const u32 tb = (MODE != 1 ? base_idx[i] : base0 + i) * MSM_POS;
         sc_for_each_naf_digit<NAF>(s, [&](u32 pos, u32 mag, u32 neg) {
             u32 at = atomicAdd(&cursor[key(i, mag)], 1u);
             sorted[at] = (tb + pos) | (neg << 31);
@@ -285,7 +288,7 @@ template <int MODE>
 __global__ __launch_bounds__(SORT_T) void k_msm_sort_staged(const u32* __restrict__ scal_a, const u32* __restrict__ aux, u32 n_total, u32 n_idx_sets,
                                                              u32 n_sub, u32 split, u32* __restrict__ sorted_all, u32* __restrict__ cursor_all,
                                                              const u32* __restrict__ msm_map, const u32* __restrict__ n_active, u32 CAP, u32* __restrict__ ticket) {
-    constexpr int K = msm_geom<MODE>::K, NAF = msm_geom<MODE>::NAF, W = msm_geom<MODE>::W, G = K / SORT_T;
+    constexpr int K = msm_geom<MODE>::K, NAF = msm_geom<MODE>::NAF, W = msm_geom<MODE>::W, G = K >= SORT_T ? K / SORT_T : 1;  // buckets per lane of the scan (lanes past K idle)
     extern __shared__ u32 stage[];  // [CAP] entries: the image of one window
     __shared__ u32 start[K + 2];  // start[k] = position of bucket k's first entry (k = 1..K), start[K + 1] = number of entries
     __shared__ u32 fill[K + 1];   // histogram, then entries placed so far per bucket
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(SORT_T) void k_msm_sort_staged(const u32* __restric
     const u32* sbase;
     const u32* base_idx = nullptr;
     u32 base0 = 0;
-    if (MODE == 0) {
+    if (MODE != 1) {
         const size_t src = msm_map ? (size_t)msm_map[msm] : msm;
         sbase = scal_a + (src * (size_t)n_total + i0) * 8;
         base_idx = aux + (size_t)(msm % n_idx_sets) * n_total + i0;
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(SORT_T) void k_msm_sort_staged(const u32* __restric
         base0 = (side ? BBP_BASE_H0 : BBP_BASE_G0) + i0;
     }
     u32* sorted = sorted_all + work * (size_t)n_sub * W;
-    auto key = [&](u32 i, u32 mag) -> u32 { return (MODE == 0 ? 0u : ((i0 + i) & (FOLD_CLS - 1)) * FOLD_M) + ((mag + 1) >> 1); };
+    auto key = [&](u32 i, u32 mag) -> u32 { return (MODE != 1 ? 0u : ((i0 + i) & (FOLD_CLS - 1)) * FOLD_M) + ((mag + 1) >> 1); };
 
     for (int k = tid; k <= K; k += SORT_T) fill[k] = 0;
     __syncthreads();
@@ -319,14 +322,15 @@ __global__ __launch_bounds__(SORT_T) void k_msm_sort_staged(const u32* __restric
         const uint4* sp = reinterpret_cast<const uint4*>(sbase + (size_t)i * 8);
         uint4 lo = sp[0], hi = sp[1];
         const u32 s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        if (MODE == 0 && base_idx[i] == MSM_SKIP_BASE) continue;
+        if (MODE != 1 && base_idx[i] == MSM_SKIP_BASE) continue;
         sc_for_each_naf_digit<NAF>(s, [&](u32, u32 mag, u32) { atomicAdd(&fill[key(i, mag)], 1u); });
     }
     __syncthreads();
     // B. bucket start offsets (block-wide exclusive scan as in k_msm_sort), counters back to zero
     {
         u32 local = 0;
-        for (int r = 1; r <= G; r++) local += fill[tid * G + r];
+        for (int r = 1; r <= G; r++)
+            if (tid * G + r <= K) local += fill[tid * G + r];
         const int lane = tid & 63, wave = tid >> 6;
         u32 incl = local;
 #pragma unroll
@@ -349,12 +353,13 @@ __global__ __launch_bounds__(SORT_T) void k_msm_sort_staged(const u32* __restric
         __syncthreads();
         u32 base = part[wave] + incl - local;
         for (int r = 1; r <= G; r++) {
+            if (tid * G + r > K) break;
             const u32 c = fill[tid * G + r];
             start[tid * G + r] = base;
             fill[tid * G + r] = 0;
             base += c;
         }
-        if (tid == SORT_T - 1) start[K + 1] = base;
+        if (tid == SORT_T - 1) start[K + 1] = base;  // (lanes past K carry the grand total: `local` is 0 for them)
         if (tid == 0) start[0] = 0;
     }
     __syncthreads();
@@ -377,8 +382,8 @@ __global__ __launch_bounds__(SORT_T) void k_msm_sort_staged(const u32* __restric
                 const uint4* sp = reinterpret_cast<const uint4*>(sbase + (size_t)i * 8);
                 uint4 lo4 = sp[0], hi4 = sp[1];
                 const u32 s[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
-                if (MODE == 0 && base_idx[i] == MSM_SKIP_BASE) continue;
-                const u32 tb = (MODE == 0 ? base_idx[i] : base0 + i) * MSM_POS;
+                if (MODE != 1 && base_idx[i] == MSM_SKIP_BASE) continue;
+                const u32 tb = (MODE != 1 ? base_idx[i] : base0 + i) * MSM_POS;
                 sc_for_each_naf_digit<NAF>(s, [&](u32 pos, u32 mag, u32 neg) {
                     const u32 k = key(i, mag);
                     if (k >= kb && k < ke) {
@@ -584,7 +589,7 @@ __global__ __launch_bounds__(MSM_T) void k_msm_fold(const u32* __restrict__ curs
     ge* bsum = bsum_all + msm * (size_t)K;
     const ge* psum = psum_all + msm * (size_t)ACC_T;
 #ifdef BBP_KO_FOLD  // timing experiment (wrong results): the fold does nothing but write some point per output
-    if (MODE == 0) { if (tid == 0) out[msm] = bsum[0]; }
+    if (MODE != 1) { if (tid == 0) out[msm] = bsum[0]; }
     else if (tid < FOLD_CLS) out[msm * FOLD_CLS + tid] = bsum[tid];
     return;
 #endif
@@ -626,7 +631,7 @@ __global__ __launch_bounds__(MSM_T) void k_msm_fold(const u32* __restrict__ curs
         total = ge_add(total, running);
     }
 
-    if constexpr (MODE == 0) {
+    if constexpr (MODE != 1) {
         // E. cross-lane fold: W = sum_k k S_k = sum_t total_t + G * sum_{t>=1} suffix_t, suffix_t = sum_{u>=t} running_u
         const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll 1
@@ -645,7 +650,9 @@ __global__ __launch_bounds__(MSM_T) void k_msm_fold(const u32* __restrict__ curs
         ge x = total;
         if (tid >= 1) {
             ge s = running;
-            for (int i = 0; i < MSM_LOG_G; i++) ge_dbl_nc(s, s);
+            constexpr int LOG_G = G == 1 ? 0 : G == 2 ? 1 : G == 4 ? 2 : G == 8 ? 3 : G == 16 ? 4 : -1;  // G buckets per lane: W = sum total_t + G * sum_{t>=1} suffix_t
+            static_assert(LOG_G >= 0, "buckets per fold lane must be a power of two up to 16");
+            for (int i = 0; i < LOG_G; i++) ge_dbl_nc(s, s);
             ge_add_nc(x, x, s);
         }
 #pragma unroll 1
@@ -937,7 +944,8 @@ static MsmScratch msm_scratch_layout(void* base, size_t n_msm, size_t n_terms, s
 }
 size_t msm_scratch_bytes(uint32_t n_msm, uint32_t n_terms) {
     const u32 split = msm_split(n_msm, n_terms), n_sub = (n_terms + split - 1) / split;
-    const size_t a = msm_scratch_layout(nullptr, (size_t)n_msm * split, n_sub, MSM_W, MSM_K).bytes;
+    size_t a = msm_scratch_layout(nullptr, (size_t)n_msm * split, n_sub, MSM_W, MSM_K).bytes;
+    if (split > 1) a = std::max(a, msm_scratch_layout(nullptr, (size_t)n_msm * split, n_sub, SMALL_W, SMALL_K).bytes);  // split MSMs: the small geometry (or, BBP_MSM_SMALL=0, the large one)
     const size_t b = msm_scratch_layout(nullptr, n_msm, n_terms, MSM_W, MSM_K).bytes;  // the unsplit layout of a device-sized launch
     return a > b ? a : b;
 }
@@ -1022,6 +1030,36 @@ int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* sc
     // device-sized launches (n_active_dev: n_msm is only the upper bound of how many MSMs there are) are never split
     const u32 split = n_active_dev ? 1u : msm_split(n_msm, n_terms), n_sub = (n_terms + split - 1) / split;
     const u32 n_work = n_msm * split;
+    static const bool small_off = getenv("BBP_MSM_SMALL") && !atoi(getenv("BBP_MSM_SMALL"));  // BBP_MSM_SMALL=0: split MSMs keep the 1024-bucket geometry
+    if (split > 1 && !small_off) {
+        // SPLIT MSMs (small batches): width-9 digits into 128 buckets (context.h SMALL_*): same kernels, MODE 2
+        const MsmScratch ms = msm_scratch_layout(scratch.p, n_work, n_sub, SMALL_W, SMALL_K);
+        {
+            ScopedEvent ev(ctx, TAG_MSM_SORT, stream);
+            hipLaunchKernelGGL(k_msm_sort<2>, dim3(n_work), dim3(SORT_T), 0, stream, scalars_dev, base_idx_dev, n_terms, n_idx_sets, n_sub, split, ms.sorted, ms.cursor,
+                               msm_map_dev, n_active_dev, ms.ticket);
+            BBP_HIP_TRY(ctx, hipGetLastError());
+        }
+        if (ctx->debug_corrupt) {
+            ctx->debug_corrupt = 0;
+            hipLaunchKernelGGL(k_debug_poke, dim3(1), dim3(1), 0, stream, ms.sorted);
+            BBP_HIP_TRY(ctx, hipGetLastError());
+        }
+        {
+            ScopedEvent ev(ctx, TAG_MSM, stream);
+            hipLaunchKernelGGL(k_msm_acc<2>, dim3(acc_grid(ctx, n_work)), dim3(ACC_WG), 0, stream, ctx->ptable, ms.sorted, ms.cursor, n_sub, ms.bsum, ms.psum, ms.tmp,
+                               n_active_dev, ctx->health, n_work, ms.ticket);
+            BBP_HIP_TRY(ctx, hipGetLastError());
+        }
+        {
+            ScopedEvent evf(ctx, TAG_MSM_FOLD, stream);
+            hipLaunchKernelGGL(k_msm_fold<2>, dim3(n_work), dim3(MSM_T), 0, stream, ms.cursor, ms.bsum, ms.psum, ms.tmp, n_active_dev);
+            BBP_HIP_TRY(ctx, hipGetLastError());
+        }
+        hipLaunchKernelGGL(k_msm_reduce, dim3((n_msm * REDUCE_L + 63) / 64), dim3(64), lds_token(ctx), stream, n_msm, split, 1u, ms.tmp, out_points_dev);
+        BBP_HIP_TRY(ctx, hipGetLastError());
+        return BBP_OK;
+    }
     const MsmScratch m = msm_scratch_layout(scratch.p, n_work, n_sub, MSM_W, MSM_K);
     {
         ScopedEvent ev(ctx, TAG_MSM_SORT, stream);

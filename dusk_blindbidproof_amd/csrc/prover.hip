@@ -25,6 +25,7 @@
 
 #include "batch.h"
 #include "hosthash.h"
+#include "keccak_wave.h"
 
 namespace bbp {
 
@@ -512,15 +513,60 @@ __global__ void k_open_bulk8(u32 B, u32 rng_blocks, u32 n1, u32 count, merlin_tr
     if (live && c.first) T->cur_flags = BBP_FLAG_I | BBP_FLAG_A | BBP_FLAG_C;
 }
 
+// rng waves, third form (keccak_wave.h): one proof per wavefront, one 32-bit half of a state word per lane, bit-interleaved.
+// The draws go out as (even bits, odd bits) pairs; k_reduce_draws joins them (interleaved = 1).  Witness blocks as in k_open_bulk.
+__global__ void k_open_bulk50(u32 B, u32 rng_blocks, u32 n1, u32 count, merlin_transcript* __restrict__ rng, u32* __restrict__ raw, u32 m,
+                              u32 n_cst, const u32* __restrict__ w_terms, const u32* __restrict__ w_loff, const u32* __restrict__ w_roff,
+                              const sc* __restrict__ cst_all, const sc* __restrict__ v_all, sc* __restrict__ ai1_all, sc* __restrict__ ao1_all) {
+    if (blockIdx.x >= rng_blocks) {
+        const u32 p = (blockIdx.x - rng_blocks) * blockDim.x + threadIdx.x;
+        if (p < B) witness_gates_lane(p, m, n1, n_cst, w_terms, w_loff, w_roff, cst_all, v_all, ai1_all, ao1_all);
+        return;
+    }
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 g = t >> 6, L = t & 63u;
+    const kw_lane c = kw_setup(L);
+    const kw_iota k = kw_iota_setup(L);
+    const bool live = g < B && c.live != 0;
+    const u32 p = g < B ? g : B - 1;
+    merlin_transcript* T = rng + p;
+    u32 a = c.live ? kw_half(T->st[c.word], c.half) : 0u;
+    // per-draw constants (keccak.h merlin_rng_fill64_bulk): st[8] ^= .., st[9] ^= .., st[20] ^= ..
+    const u64 konst64 = !c.live ? 0ull : c.word == 8 ? 0x0741000000401200ull : c.word == 9 ? 0x0000000000000447ull : c.word == 20 ? 0x8000000000000000ull : 0ull;
+    const u32 konst = kw_half(konst64, c.half);
+    const bool rate = c.live && c.word < 8;
+    u32* out = raw + (size_t)p * (3 + 2 * (size_t)n1) * 16 + 16 + 2 * (c.word & 7u) + c.half;  // draw 0 was written by the prefix kernel
+    for (u32 d = 0; d < count; d++) {
+        a ^= konst;
+        a = kw_keccak_f(a, c, k);
+        if (rate) {
+            if (live) out[(size_t)d * 16] = a;
+            a = 0;
+        }
+    }
+    const auto q = __builtin_amdgcn_permlane32_swap(a, a, false, false);  // the odd halves, for the lanes of the even ones
+    if (live && c.lower) T->st[c.word] = kw_join(a, q[1]);
+    if (live && L == 0) T->cur_flags = BBP_FLAG_I | BBP_FLAG_A | BBP_FLAG_C;
+}
+
 // draw j of proof p -> its scalar slot: 0 -> ai1[0], 1 -> ao1[0], 2 -> s1[0], j >= 3 -> s1[1 + (j - 3)]
-__global__ void k_reduce_draws(u32 B, u32 n1, const u32* __restrict__ raw, sc* __restrict__ ai1, sc* __restrict__ ao1, sc* __restrict__ s1) {
+// interleaved: draws 1.. were written by k_open_bulk50 as (even bits, odd bits) pairs per 64-bit word
+__global__ void k_reduce_draws(u32 B, u32 n1, const u32* __restrict__ raw, sc* __restrict__ ai1, sc* __restrict__ ao1, sc* __restrict__ s1, u32 interleaved) {
     const u32 per = 3 + 2 * n1;
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B * per) return;
     u32 p = t / per, j = t % per;
     const uint4* q = reinterpret_cast<const uint4*>(raw + (size_t)t * 16);
     uint4 a = q[0], b = q[1], c = q[2], d = q[3];
-    const u32 w[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+    u32 w[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+    if (interleaved && j > 0) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const u64 v = kw_join(w[2 * i], w[2 * i + 1]);
+            w[2 * i] = (u32)v;
+            w[2 * i + 1] = (u32)(v >> 32);
+        }
+    }
     sc v = sc_from_wide(w);
     sc* dst = j == 0 ? &ai1[(size_t)p * (1 + 2 * n1)] : j == 1 ? &ao1[(size_t)p * (1 + n1)] : &s1[(size_t)p * (1 + 2 * n1) + (j - 2)];
     st_sc(dst, v);
@@ -1466,6 +1512,7 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
         if ((rc = commit_launch(ctx, B * m, bd.v, bd.vb, m, m, m, bd.pts, m + 8, s))) return rc;
         LAUNCH(ctx, TAG_ENCODE, k_encode_strided, cdiv(B * m, 64), 64, s, B * m, m, bd.pts, m + 8, bd.enc, encw, 0u);
         const bool coop = ctx->rng_coop < 0 ? B <= (u32)ctx->rng_coop_below : ctx->rng_coop != 0;
+        u32 interleaved = 0;  // the draws' layout in `raw` (k_open_bulk50 writes bit-interleaved halves)
         if (!coop) {
             LAUNCH_LDS(ctx, TAG_RNG, k_open_serial, 2 * cdiv(B, sblk), sblk, hog, s, B, cdiv(B, sblk), m, n1, prefix, bd.enc, ent_dev, bd.vb,
                        (u32*)ctx->raw[sidx].p, bd.tr, bd.rng, c.n_cst, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v, bd.ai1, bd.ao1, 0u);
@@ -1480,12 +1527,19 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
             // four above 256 proofs (384: 12.8 k -> 14.8 k, 512: 14.6 k -> 16.5 k against the single-lane chain)
             const u32 cblk = ctx->rng_block > 0 ? (u32)ctx->rng_block : (B <= 128 ? 64u : B <= 256 ? 128u : 256u);
             if (ctx->rng_dpp) {
-                // one proof per wavefront (k_open_bulk8): the same number of proofs per reserved CU needs twice the lanes
+                // one proof per wavefront (k_open_bulk50, or BBP_RNG_DPP=1: k_open_bulk8): the same number of proofs per reserved CU needs twice the lanes
+                const void* kfn = ctx->rng_dpp >= 2 ? (const void*)k_open_bulk50 : (const void*)k_open_bulk8;
                 u32 hog8 = 0;
-                if ((rc = serial_lds_bytes(ctx, (const void*)k_open_bulk8, &hog8))) return rc;
+                if ((rc = serial_lds_bytes(ctx, kfn, &hog8))) return rc;
                 const u32 cblk8 = 2 * cblk > 1024u ? 1024u : 2 * cblk, nb_rng = cdiv(B * 64, cblk8), nb_wit = cdiv(B, cblk8);
-                LAUNCH_LDS(ctx, TAG_RNG, k_open_bulk8, nb_rng + nb_wit, cblk8, hog8, s, B, nb_rng, n1, 2 + 2 * n1, bd.rng, (u32*)ctx->raw[sidx].p, m,
-                           c.n_cst, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v, bd.ai1, bd.ao1);
+                if (ctx->rng_dpp >= 2) {
+                    interleaved = 1;
+                    LAUNCH_LDS(ctx, TAG_RNG, k_open_bulk50, nb_rng + nb_wit, cblk8, hog8, s, B, nb_rng, n1, 2 + 2 * n1, bd.rng, (u32*)ctx->raw[sidx].p, m,
+                               c.n_cst, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v, bd.ai1, bd.ao1);
+                } else {
+                    LAUNCH_LDS(ctx, TAG_RNG, k_open_bulk8, nb_rng + nb_wit, cblk8, hog8, s, B, nb_rng, n1, 2 + 2 * n1, bd.rng, (u32*)ctx->raw[sidx].p, m,
+                               c.n_cst, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v, bd.ai1, bd.ao1);
+                }
             } else {
                 u32 hogb = 0;
                 if ((rc = serial_lds_bytes(ctx, (const void*)k_open_bulk, &hogb))) return rc;
@@ -1494,7 +1548,7 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
                            c.n_cst, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v, bd.ai1, bd.ao1);
             }
         }
-        LAUNCH(ctx, TAG_RNG, k_reduce_draws, cdiv((u32)(B * n_draws), 128), 128, s, B, n1, (const u32*)ctx->raw[sidx].p, bd.ai1, bd.ao1, bd.s1);
+        LAUNCH(ctx, TAG_RNG, k_reduce_draws, cdiv((u32)(B * n_draws), 128), 128, s, B, n1, (const u32*)ctx->raw[sidx].p, bd.ai1, bd.ao1, bd.s1, interleaved);
         BBP_HIP_TRY(ctx, hipEventRecord(ctx->ev_open[par], s));
         ctx->ev_open_valid[par] = true;
     }

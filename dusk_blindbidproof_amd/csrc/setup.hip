@@ -274,7 +274,7 @@ static int32_t init_body(int32_t device, bbp_ctx** out) {
     if (const char* e = getenv("BBP_TAIL_ROUND")) ctx->tail_round = atoi(e) == bbp::FOLD_ROUND ? bbp::FOLD_ROUND : 12;
     if (const char* e = getenv("BBP_STAGGER")) ctx->stagger_mode = atoi(e);
     if (const char* e = getenv("BBP_RNG_COOP")) ctx->rng_coop = atoi(e) != 0;
-    if (const char* e = getenv("BBP_RNG_DPP")) ctx->rng_dpp = atoi(e) != 0;
+    if (const char* e = getenv("BBP_RNG_DPP")) ctx->rng_dpp = atoi(e);
     if (const char* e = getenv("BBP_TAIL_SMALL_BELOW")) ctx->tail_small_below = atoi(e);
     if (const char* e = getenv("BBP_RNG_COOP_BELOW")) ctx->rng_coop_below = atoi(e);
     if (const char* e = getenv("BBP_RNG_BLOCK")) {
