@@ -486,6 +486,7 @@ __global__ void k_open_bulk8(u32 B, u32 rng_blocks, u32 n1, u32 count, merlin_tr
     }
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     const u32 g = t >> 6, L = t & 63u;
+    if (g >= B) return;  // spare wavefront of the last workgroup (see k_open_bulk50)
     const coop8_lane c = coop8_setup(L);
     const bool live = g < B && c.live != 0;
     const u32 p = g < B ? g : B - 1;
@@ -525,6 +526,7 @@ __global__ void k_open_bulk50(u32 B, u32 rng_blocks, u32 n1, u32 count, merlin_t
     }
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     const u32 g = t >> 6, L = t & 63u;
+    if (g >= B) return;  // a spare wavefront of the last workgroup (no barrier in this kernel): it would run a whole chain beside a live one, on the same LDS crossbar
     const kw_lane c = kw_setup(L);
     const kw_iota k = kw_iota_setup(L);
     const bool live = g < B && c.live != 0;
