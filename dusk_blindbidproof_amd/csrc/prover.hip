@@ -1493,6 +1493,7 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
     const size_t n_draws = 3 + 2 * (size_t)n1;
     if ((rc = dev_reserve(ctx, ctx->raw[sidx], (size_t)B * n_draws * 64))) return rc;
     hipStream_t main_s = s;
+    bool traced_coop = false;  // (BBP_TRACE_PROVE) the draw chain ran on a wavefront per proof
     BBP_HIP_TRY(ctx, hipEventRecord(ctx->ev_entry[par], main_s));
     {
         hipStream_t s = sidx ? ctx->side2 : ctx->side;  // opening stage
@@ -1513,7 +1514,12 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
         LAUNCH(ctx, TAG_TRANSCRIPT, k_load_blindings, cdiv(B * m, 64), 64, s, B, m, ent_dev, bd.vb);
         if ((rc = commit_launch(ctx, B * m, bd.v, bd.vb, m, m, m, bd.pts, m + 8, s))) return rc;
         LAUNCH(ctx, TAG_ENCODE, k_encode_strided, cdiv(B * m, 64), 64, s, B * m, m, bd.pts, m + 8, bd.enc, encw, 0u);
-        const bool coop = ctx->rng_coop < 0 ? B <= (u32)ctx->rng_coop_below : ctx->rng_coop != 0;
+        // one wavefront per proof for the draw chain: always for batches up to rng_coop_below proofs; for larger ones (up to
+        // rng_coop_idle_below) only when NO earlier prove call is on the device -- a lone 1024-proof call then returns after 58
+        // instead of 81 ms, while a caller that keeps the device busy keeps the single-lane chain (a wavefront per proof costs a
+        // full pipeline 1-2 % of its throughput: two host threads 22.2 k -> 21.8 k proofs/s)
+        const bool coop = ctx->rng_coop < 0 ? B <= (u32)ctx->rng_coop_below || (inflight == 0 && B <= (u32)ctx->rng_coop_idle_below) : ctx->rng_coop != 0;
+        traced_coop = coop;
         u32 interleaved = 0;  // the draws' layout in `raw` (k_open_bulk50 writes bit-interleaved halves)
         if (!coop) {
             LAUNCH_LDS(ctx, TAG_RNG, k_open_serial, 2 * cdiv(B, sblk), sblk, hog, s, B, cdiv(B, sblk), m, n1, prefix, bd.enc, ent_dev, bd.vb,
@@ -1566,7 +1572,7 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
     // one of the three internal slice streams in rotation (own scratch slot each, like slices): up to three calls' chains in
     // flight; the caller's stream only waits for the result.
     const bool rotate = dual && ((ctx->rotate_below > 0 && B <= (u32)ctx->rotate_below) || (deep && B > (u32)ctx->rotate_below));
-    if (ctx->trace_prove) fprintf(stderr, "prove call %u: B %u inflight %d deep %d behind_sliced %d dual %d rotate %d par %d\n", call, B, inflight, (int)deep, (int)behind_sliced, (int)dual, (int)rotate, par);
+    if (ctx->trace_prove) fprintf(stderr, "prove call %u: B %u inflight %d deep %d behind_sliced %d dual %d rotate %d par %d coop %d\n", call, B, inflight, (int)deep, (int)behind_sliced, (int)dual, (int)rotate, par, (int)traced_coop);
     if (rotate) {
         const int hs = 1 + (int)(call % (u32)(bbp_ctx::MAX_SLICES - 1));
         hipStream_t ls = ctx->lane[hs];

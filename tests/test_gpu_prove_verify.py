@@ -519,6 +519,54 @@ def test_deep_pipeline_takes_the_rotating_path_with_the_same_bytes(bbp, oc, capf
         c2.close()
 
 
+def test_a_lone_large_call_takes_the_cooperative_draw_chain(bbp, oc, capfd):
+    """A batch above the cooperative threshold still gets one wavefront per proof for its TranscriptRng chain when it finds the
+    device without an earlier prove call (prover.hip `rng_coop_idle_below`); the calls queued behind it keep the single-lane chain.
+    Same bytes either way: every call must reproduce the solo records, the last record the C oracle's."""
+    import os
+    import torch
+    dev = torch.device("cuda", 0)
+    knobs = {"BBP_RNG_COOP_BELOW": "16", "BBP_RNG_COOP_IDLE_BELOW": "4096", "BBP_TRACE_PROVE": "1"}
+    old = {k: os.environ.get(k) for k in knobs}
+    os.environ.update(knobs)
+    try:
+        c2 = bbp.Context(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    try:
+        N, B = 2, 90
+        rs_ = bbp.record_size(N)
+        ins, ents, _ = _synth_batch(c2, B, N, seed=1700)
+        d_in = torch.frombuffer(bytearray(b"".join(ins)), dtype=torch.uint8).to(dev)
+        d_ent = torch.frombuffer(bytearray(b"".join(ents)), dtype=torch.uint8).to(dev)
+        solo, st = c2.prove_batch(B, N, b"".join(ins), b"".join(ents))
+        assert st == [0] * B
+        rc, exp = oc.prove(ins[B - 1][:224], ins[B - 1][224:224 + 32 * N], int.from_bytes(ins[B - 1][-8:], "little"), ents[B - 1])
+        assert rc == 0 and solo[(B - 1) * rs_:] == exp
+        torch.cuda.synchronize()
+        capfd.readouterr()
+        s = torch.cuda.current_stream().cuda_stream
+        outs = []
+        for it in range(4):
+            out = torch.zeros(B * rs_, dtype=torch.uint8, device=dev)
+            c2.prove_batch_dev(B, N, d_in.data_ptr(), d_ent.data_ptr(), out.data_ptr(), s)
+            outs.append(out)
+        torch.cuda.synchronize()
+        for it, out in enumerate(outs):
+            assert bytes(out.cpu().numpy().tobytes()) == solo, it
+        trace = [l for l in capfd.readouterr().err.splitlines() if l.startswith("prove call")]
+        assert len(trace) == 4
+        assert " inflight 0 " in trace[0] and trace[0].rstrip().endswith("coop 1")   # the device was idle: a wavefront per proof
+        assert any(l.rstrip().endswith("coop 0") for l in trace[1:])                    # behind it: the single-lane chain
+        assert c2.health() == 0
+    finally:
+        c2.close()
+
+
 def test_pipelined_calls_with_different_list_lengths(ctx, oc, bbp):
     """Consecutive device calls with different N use different compiled circuits (index lists, constraint tables) while the
     previous call is still in flight: outputs must equal the solo runs and the oracle's record."""
