@@ -121,8 +121,8 @@ __global__ void k_witness_head(u32 B, u32 n_items, u32 n_cst, const u8* __restri
 }
 
 // gates: one lane interprets the compiled gadget program of its proof (sequential MiMC chains) -> a_L, a_R, a_O
-__device__ void witness_gates_lane(u32 p, u32 m, u32 n_mul, u32 n_cst, const u32* __restrict__ w_terms, const u32* __restrict__ w_loff,
-                                   const u32* __restrict__ w_roff, const sc* __restrict__ cst_all, const sc* __restrict__ v_all,
+__device__ void witness_gates_lane(u32 p, u32 m, u32 n_mul, u32 n_cst, const u32* w_terms, const u32* w_loff,
+                                   const u32* w_roff, const sc* __restrict__ cst_all, const sc* __restrict__ v_all,
                                    sc* __restrict__ ai1_all, sc* __restrict__ ao1_all) {
     const sc* cst = cst_all + (size_t)p * n_cst;
     const sc* v = v_all + (size_t)p * m;
@@ -146,6 +146,33 @@ __device__ void witness_gates_lane(u32 p, u32 m, u32 n_mul, u32 n_cst, const u32
         st_sc(&aR[i], lr[1]);
         st_sc(&aO[i], sc_mul(lr[0], lr[1]));
     }
+}
+
+// The witness blocks of the cooperative opening launches (one lane per proof).  The interpreter's time is its dependent loads --
+// offsets -> term word -> value, 5200 terms, and every value a MiMC round needs was stored by the multiplier before it: 6.6 ms per
+// proof, MORE than the draw chain beside it since keccak_wave.h.  The program (offsets + term words, the same for every proof of
+// the launch) is therefore staged ONCE per workgroup in the dynamic LDS these launches reserve anyway (the CU is theirs alone):
+// 6.6 -> 5.9 ms, level with the chain.  (Fetching a multiplier's eight term words and values together instead: 7.5 ms -- the
+// store -> load round trips of the values are the chain, not the number of loads; a value ring in LDS is what would cut it.)
+// lds_bytes: what the launch was given; a program that does not fit (or BBP_SERIAL_LDS=0) is read from global memory as before.
+__device__ void witness_gates_block(u32 first_proof, u32 B, u32 m, u32 n_mul, u32 n_cst, const u32* __restrict__ w_terms, const u32* __restrict__ w_loff,
+                                    const u32* __restrict__ w_roff, const sc* __restrict__ cst_all, const sc* __restrict__ v_all,
+                                    sc* __restrict__ ai1_all, sc* __restrict__ ao1_all, u32 lds_bytes) {
+    extern __shared__ u32 prog[];
+    const u32 n_terms = w_loff[n_mul];
+    const bool staged = (size_t)(2 * n_mul + 1 + n_terms) * 4 <= lds_bytes;  // uniform over the launch
+    const u32 *lo = w_loff, *ro = w_roff, *tw = w_terms;
+    if (staged) {
+        for (u32 i = threadIdx.x; i <= n_mul; i += blockDim.x) prog[i] = w_loff[i];
+        for (u32 i = threadIdx.x; i < n_mul; i += blockDim.x) prog[n_mul + 1 + i] = w_roff[i];
+        for (u32 i = threadIdx.x; i < n_terms; i += blockDim.x) prog[2 * n_mul + 1 + i] = w_terms[i];
+        __syncthreads();
+        lo = prog;
+        ro = prog + n_mul + 1;
+        tw = prog + 2 * n_mul + 1;
+    }
+    const u32 p = first_proof + threadIdx.x;
+    if (p < B) witness_gates_lane(p, m, n_mul, n_cst, tw, lo, ro, cst_all, v_all, ai1_all, ao1_all);
 }
 
 // MiMC constants into every proof's constant table (one lane per (proof, round))
@@ -353,10 +380,9 @@ __device__ __forceinline__ u64 coop_keccak_f(u64 a, const coop_lane& c) {
 // rng lanes: (B proofs) x 32 lanes, two proofs per wavefront; witness lanes (blocks >= rng_blocks): one lane per proof as before
 __global__ void k_open_bulk(u32 B, u32 rng_blocks, u32 n1, u32 count, merlin_transcript* __restrict__ rng, u32* __restrict__ raw, u32 m,
                             u32 n_cst, const u32* __restrict__ w_terms, const u32* __restrict__ w_loff, const u32* __restrict__ w_roff,
-                            const sc* __restrict__ cst_all, const sc* __restrict__ v_all, sc* __restrict__ ai1_all, sc* __restrict__ ao1_all) {
+                            const sc* __restrict__ cst_all, const sc* __restrict__ v_all, sc* __restrict__ ai1_all, sc* __restrict__ ao1_all, u32 lds_bytes) {
     if (blockIdx.x >= rng_blocks) {
-        const u32 p = (blockIdx.x - rng_blocks) * blockDim.x + threadIdx.x;
-        if (p < B) witness_gates_lane(p, m, n1, n_cst, w_terms, w_loff, w_roff, cst_all, v_all, ai1_all, ao1_all);
+        witness_gates_block((blockIdx.x - rng_blocks) * blockDim.x, B, m, n1, n_cst, w_terms, w_loff, w_roff, cst_all, v_all, ai1_all, ao1_all, lds_bytes);
         return;
     }
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -478,10 +504,9 @@ __device__ __forceinline__ void coop8_keccak_f(u32& lo, u32& hi, const coop8_lan
 // rng waves: one proof per wavefront (state lanes 8 y + x); witness blocks as in k_open_bulk
 __global__ void k_open_bulk8(u32 B, u32 rng_blocks, u32 n1, u32 count, merlin_transcript* __restrict__ rng, u32* __restrict__ raw, u32 m,
                              u32 n_cst, const u32* __restrict__ w_terms, const u32* __restrict__ w_loff, const u32* __restrict__ w_roff,
-                             const sc* __restrict__ cst_all, const sc* __restrict__ v_all, sc* __restrict__ ai1_all, sc* __restrict__ ao1_all) {
+                             const sc* __restrict__ cst_all, const sc* __restrict__ v_all, sc* __restrict__ ai1_all, sc* __restrict__ ao1_all, u32 lds_bytes) {
     if (blockIdx.x >= rng_blocks) {
-        const u32 p = (blockIdx.x - rng_blocks) * blockDim.x + threadIdx.x;
-        if (p < B) witness_gates_lane(p, m, n1, n_cst, w_terms, w_loff, w_roff, cst_all, v_all, ai1_all, ao1_all);
+        witness_gates_block((blockIdx.x - rng_blocks) * blockDim.x, B, m, n1, n_cst, w_terms, w_loff, w_roff, cst_all, v_all, ai1_all, ao1_all, lds_bytes);
         return;
     }
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -518,10 +543,9 @@ __global__ void k_open_bulk8(u32 B, u32 rng_blocks, u32 n1, u32 count, merlin_tr
 // The draws go out as (even bits, odd bits) pairs; k_reduce_draws joins them (interleaved = 1).  Witness blocks as in k_open_bulk.
 __global__ void k_open_bulk50(u32 B, u32 rng_blocks, u32 n1, u32 count, merlin_transcript* __restrict__ rng, u32* __restrict__ raw, u32 m,
                               u32 n_cst, const u32* __restrict__ w_terms, const u32* __restrict__ w_loff, const u32* __restrict__ w_roff,
-                              const sc* __restrict__ cst_all, const sc* __restrict__ v_all, sc* __restrict__ ai1_all, sc* __restrict__ ao1_all) {
+                              const sc* __restrict__ cst_all, const sc* __restrict__ v_all, sc* __restrict__ ai1_all, sc* __restrict__ ao1_all, u32 lds_bytes) {
     if (blockIdx.x >= rng_blocks) {
-        const u32 p = (blockIdx.x - rng_blocks) * blockDim.x + threadIdx.x;
-        if (p < B) witness_gates_lane(p, m, n1, n_cst, w_terms, w_loff, w_roff, cst_all, v_all, ai1_all, ao1_all);
+        witness_gates_block((blockIdx.x - rng_blocks) * blockDim.x, B, m, n1, n_cst, w_terms, w_loff, w_roff, cst_all, v_all, ai1_all, ao1_all, lds_bytes);
         return;
     }
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -538,6 +562,9 @@ __global__ void k_open_bulk50(u32 B, u32 rng_blocks, u32 n1, u32 count, merlin_t
     const u32 konst = kw_half(konst64, c.half);
     const bool rate = c.live && c.word < 8;
     u32* out = raw + (size_t)p * (3 + 2 * (size_t)n1) * 16 + 16 + 2 * (c.word & 7u) + c.half;  // draw 0 was written by the prefix kernel
+#ifdef BBP_KO_RNG_CHAIN  // timing experiment (wrong results): no draws, the launch lasts as long as its witness blocks
+    count = 0;
+#endif
     for (u32 d = 0; d < count; d++) {
         a ^= konst;
         a = kw_keccak_f(a, c, k);
@@ -1543,17 +1570,17 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
                 if (ctx->rng_dpp >= 2) {
                     interleaved = 1;
                     LAUNCH_LDS(ctx, TAG_RNG, k_open_bulk50, nb_rng + nb_wit, cblk8, hog8, s, B, nb_rng, n1, 2 + 2 * n1, bd.rng, (u32*)ctx->raw[sidx].p, m,
-                               c.n_cst, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v, bd.ai1, bd.ao1);
+                               c.n_cst, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v, bd.ai1, bd.ao1, hog8);
                 } else {
                     LAUNCH_LDS(ctx, TAG_RNG, k_open_bulk8, nb_rng + nb_wit, cblk8, hog8, s, B, nb_rng, n1, 2 + 2 * n1, bd.rng, (u32*)ctx->raw[sidx].p, m,
-                               c.n_cst, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v, bd.ai1, bd.ao1);
+                               c.n_cst, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v, bd.ai1, bd.ao1, hog8);
                 }
             } else {
                 u32 hogb = 0;
                 if ((rc = serial_lds_bytes(ctx, (const void*)k_open_bulk, &hogb))) return rc;
                 const u32 nb_rng = cdiv(B * 32, cblk), nb_wit = cdiv(B, cblk);
                 LAUNCH_LDS(ctx, TAG_RNG, k_open_bulk, nb_rng + nb_wit, cblk, hogb, s, B, nb_rng, n1, 2 + 2 * n1, bd.rng, (u32*)ctx->raw[sidx].p, m,
-                           c.n_cst, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v, bd.ai1, bd.ao1);
+                           c.n_cst, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v, bd.ai1, bd.ao1, hogb);
             }
         }
         LAUNCH(ctx, TAG_RNG, k_reduce_draws, cdiv((u32)(B * n_draws), 128), 128, s, B, n1, (const u32*)ctx->raw[sidx].p, bd.ai1, bd.ao1, bd.s1, interleaved);
