@@ -1030,8 +1030,7 @@ int32_t msm_launch(bbp_ctx* ctx, uint32_t n_msm, uint32_t n_terms, const u32* sc
     // device-sized launches (n_active_dev: n_msm is only the upper bound of how many MSMs there are) are never split
     const u32 split = n_active_dev ? 1u : msm_split(n_msm, n_terms), n_sub = (n_terms + split - 1) / split;
     const u32 n_work = n_msm * split;
-    static const bool small_off = getenv("BBP_MSM_SMALL") && !atoi(getenv("BBP_MSM_SMALL"));  // BBP_MSM_SMALL=0: split MSMs keep the 1024-bucket geometry
-    if (split > 1 && !small_off) {
+    if (split > 1 && ctx->msm_small) {  // BBP_MSM_SMALL=0: split MSMs keep the 1024-bucket geometry
         // SPLIT MSMs (small batches): width-9 digits into 128 buckets (context.h SMALL_*): same kernels, MODE 2
         const MsmScratch ms = msm_scratch_layout(scratch.p, n_work, n_sub, SMALL_W, SMALL_K);
         {

@@ -422,6 +422,36 @@ def test_engine_schedules_give_identical_bytes(bbp, oc, knobs):
         c2.close()
 
 
+@pytest.mark.parametrize("small", ["1", "0"])
+def test_split_msm_geometries_give_identical_bytes(bbp, oc, small):
+    """Launches of fewer than 128 MSMs are cut into sub-MSMs; those use 128 buckets and width-9 digits (msm.hip msm_geom<2>) or,
+    BBP_MSM_SMALL=0, the 1024 buckets of the unsplit kernels.  Either way the records are the C oracle's, for one proof (sixteen
+    sub-MSMs per MSM) and for a batch that is cut in fewer pieces."""
+    import os
+    old = os.environ.get("BBP_MSM_SMALL")
+    os.environ["BBP_MSM_SMALL"] = small
+    try:
+        c2 = bbp.Context(0)
+    finally:
+        if old is None:
+            os.environ.pop("BBP_MSM_SMALL", None)
+        else:
+            os.environ["BBP_MSM_SMALL"] = old
+    try:
+        for B, N, seed in ((1, 8, 77), (23, 3, 78), (100, 1, 79)):
+            ins, ents, vins = _synth_batch(c2, B, N, seed=seed)
+            rs_ = bbp.record_size(N)
+            out, st = c2.prove_batch(B, N, b"".join(ins), b"".join(ents))
+            assert st == [0] * B
+            cout, cst = oc.prove_many(b"".join(ins), b"".join(ents), B, N, threads=8)
+            assert cst == [0] * B and out == cout, (B, N)
+            vin = b"".join(out[i * rs_:(i + 1) * rs_] + v[0] + v[1] + v[2] + v[3] for i, v in enumerate(vins))
+            assert c2.verify_batch(B, N, vin) == [0] * B
+        assert c2.health() == 0
+    finally:
+        c2.close()
+
+
 def test_pipelined_calls_of_mixed_batch_sizes(bbp, oc):
     """Back-to-back device calls without host synchronisation, alternating between batch sizes below and above the
     dual-opening threshold (two opening streams over three buffers vs one stream over two): every call must reproduce the
