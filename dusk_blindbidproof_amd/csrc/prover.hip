@@ -148,6 +148,64 @@ __device__ void witness_gates_lane(u32 p, u32 m, u32 n_mul, u32 n_cst, const u32
     }
 }
 
+// The same gates WITHOUT the program: the gadget wiring of the reference written out (src/gadgets.rs:6-34 proof_gadget, :37-68
+// mimc_gadget, :88-132 one_of_many_gadget, :134-140 boolean_gadget, :70-86 score_gadget; the multiplier order is the call order,
+// as in circuit.h's generic synthesis).  Values stay in registers along a MiMC chain -- the interpreter fetches every operand it
+// stored one multiplier earlier back from memory, which is its whole running time (5.9 ms per proof against 1.1 here).  Both
+// forms must produce the same a_L, a_R, a_O (canonical scalars): every record test compares the proof bytes with the oracle under
+// each (BBP_WITNESS_NATIVE=0 keeps the interpreter; launches with one lane per proof for the draw chain always use it).
+__device__ sc witness_mimc_native(sc x, const sc& key, const sc* __restrict__ cst, sc* __restrict__ aL, sc* __restrict__ aR, sc* __restrict__ aO, u32 base) {
+    for (u32 i = 0; i < (u32)BBP_MIMC_ROUNDS; i++) {
+        const sc a = sc_add(sc_add(x, key), ld_sc(&cst[circuit::CST_MIMC0 + i]));
+        const sc a2 = sc_mul(a, a), a3 = sc_mul(a2, a), a4 = sc_mul(a2, a2), a7 = sc_mul(a4, a3);
+        const u32 j = base + 4 * i;
+        st_sc(&aL[j], a);      st_sc(&aR[j], a);      st_sc(&aO[j], a2);
+        st_sc(&aL[j + 1], a2); st_sc(&aR[j + 1], a);  st_sc(&aO[j + 1], a3);
+        st_sc(&aL[j + 2], a2); st_sc(&aR[j + 2], a2); st_sc(&aO[j + 2], a4);
+        st_sc(&aL[j + 3], a4); st_sc(&aR[j + 3], a3); st_sc(&aO[j + 3], a7);
+        x = a7;
+    }
+    return sc_add(x, key);
+}
+__device__ void witness_gates_native_lane(u32 p, u32 m, u32 n_mul, u32 n_cst, const sc* __restrict__ cst_all, const sc* __restrict__ v_all,
+                                          sc* __restrict__ ai1_all, sc* __restrict__ ao1_all) {
+    const sc* cst = cst_all + (size_t)p * n_cst;
+    const sc* v = v_all + (size_t)p * m;
+    sc* aL = ai1_all + (size_t)p * (1 + 2 * n_mul) + 1;
+    sc* aR = aL + n_mul;
+    sc* aO = ao1_all + (size_t)p * (1 + n_mul) + 1;
+    const u32 N = m - 4, R4 = 4 * (u32)BBP_MIMC_ROUNDS;
+    const sc d = ld_sc(&v[0]), k = ld_sc(&v[1]), y_inv = ld_sc(&v[3]), seed = ld_sc(&cst[circuit::CST_SEED]);
+    const sc mm = witness_mimc_native(k, sc_zero(), cst, aL, aR, aO, 0);      // m = H(k)
+    const sc x = witness_mimc_native(d, mm, cst, aL, aR, aO, R4);             // x = H(d, m)
+    u32 j = 2 * R4;
+    for (u32 i = 0; i < N; i++, j++) {                                       // toggle bits are bits: t (1 - t) = 0
+        const sc t = ld_sc(&v[4 + i]), nt = sc_sub(sc_one(), t);
+        st_sc(&aL[j], t);
+        st_sc(&aR[j], nt);
+        st_sc(&aO[j], sc_mul(t, nt));
+    }
+    for (u32 i = 0; i < N; i++, j += 2) {                                    // item_i t_i = t_i x
+        const sc t = ld_sc(&v[4 + i]), item = ld_sc(&cst[circuit::CST_ITEM0 + i]);
+        st_sc(&aL[j], item);
+        st_sc(&aR[j], t);
+        st_sc(&aO[j], sc_mul(item, t));
+        st_sc(&aL[j + 1], t);
+        st_sc(&aR[j + 1], x);
+        st_sc(&aO[j + 1], sc_mul(t, x));
+    }
+    const sc y = witness_mimc_native(seed, x, cst, aL, aR, aO, j);            // y = H(seed, x)
+    witness_mimc_native(seed, mm, cst, aL, aR, aO, j + R4);                   // z = H(seed, m): constrained against z_img, not multiplied further
+    j += 2 * R4;
+    st_sc(&aL[j], y);                                                        // score: y y_inv = 1, d y_inv = q
+    st_sc(&aR[j], y_inv);
+    st_sc(&aO[j], sc_mul(y, y_inv));
+    st_sc(&aL[j + 1], d);
+    st_sc(&aR[j + 1], y_inv);
+    st_sc(&aO[j + 1], sc_mul(d, y_inv));
+    // (j + 2 == n_mul: circuit.h's synthesis and this function count the same multipliers; checked on the host at compile time of the circuit)
+}
+
 // The witness blocks of the cooperative opening launches (one lane per proof).  The interpreter's time is its dependent loads --
 // offsets -> term word -> value, 5200 terms, and every value a MiMC round needs was stored by the multiplier before it: 6.6 ms per
 // proof, MORE than the draw chain beside it since keccak_wave.h.  The program (offsets + term words, the same for every proof of
@@ -157,7 +215,12 @@ __device__ void witness_gates_lane(u32 p, u32 m, u32 n_mul, u32 n_cst, const u32
 // lds_bytes: what the launch was given; a program that does not fit (or BBP_SERIAL_LDS=0) is read from global memory as before.
 __device__ void witness_gates_block(u32 first_proof, u32 B, u32 m, u32 n_mul, u32 n_cst, const u32* __restrict__ w_terms, const u32* __restrict__ w_loff,
                                     const u32* __restrict__ w_roff, const sc* __restrict__ cst_all, const sc* __restrict__ v_all,
-                                    sc* __restrict__ ai1_all, sc* __restrict__ ao1_all, u32 lds_bytes) {
+                                    sc* __restrict__ ai1_all, sc* __restrict__ ao1_all, u32 lds_bytes, u32 native) {
+    if (native) {
+        const u32 p = first_proof + threadIdx.x;
+        if (p < B) witness_gates_native_lane(p, m, n_mul, n_cst, cst_all, v_all, ai1_all, ao1_all);
+        return;
+    }
     extern __shared__ u32 prog[];
     const u32 n_terms = w_loff[n_mul];
     const bool staged = (size_t)(2 * n_mul + 1 + n_terms) * 4 <= lds_bytes;  // uniform over the launch
@@ -380,9 +443,9 @@ __device__ __forceinline__ u64 coop_keccak_f(u64 a, const coop_lane& c) {
 // rng lanes: (B proofs) x 32 lanes, two proofs per wavefront; witness lanes (blocks >= rng_blocks): one lane per proof as before
 __global__ void k_open_bulk(u32 B, u32 rng_blocks, u32 n1, u32 count, merlin_transcript* __restrict__ rng, u32* __restrict__ raw, u32 m,
                             u32 n_cst, const u32* __restrict__ w_terms, const u32* __restrict__ w_loff, const u32* __restrict__ w_roff,
-                            const sc* __restrict__ cst_all, const sc* __restrict__ v_all, sc* __restrict__ ai1_all, sc* __restrict__ ao1_all, u32 lds_bytes) {
+                            const sc* __restrict__ cst_all, const sc* __restrict__ v_all, sc* __restrict__ ai1_all, sc* __restrict__ ao1_all, u32 lds_bytes, u32 wit_native) {
     if (blockIdx.x >= rng_blocks) {
-        witness_gates_block((blockIdx.x - rng_blocks) * blockDim.x, B, m, n1, n_cst, w_terms, w_loff, w_roff, cst_all, v_all, ai1_all, ao1_all, lds_bytes);
+        witness_gates_block((blockIdx.x - rng_blocks) * blockDim.x, B, m, n1, n_cst, w_terms, w_loff, w_roff, cst_all, v_all, ai1_all, ao1_all, lds_bytes, wit_native);
         return;
     }
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -504,9 +567,9 @@ __device__ __forceinline__ void coop8_keccak_f(u32& lo, u32& hi, const coop8_lan
 // rng waves: one proof per wavefront (state lanes 8 y + x); witness blocks as in k_open_bulk
 __global__ void k_open_bulk8(u32 B, u32 rng_blocks, u32 n1, u32 count, merlin_transcript* __restrict__ rng, u32* __restrict__ raw, u32 m,
                              u32 n_cst, const u32* __restrict__ w_terms, const u32* __restrict__ w_loff, const u32* __restrict__ w_roff,
-                             const sc* __restrict__ cst_all, const sc* __restrict__ v_all, sc* __restrict__ ai1_all, sc* __restrict__ ao1_all, u32 lds_bytes) {
+                             const sc* __restrict__ cst_all, const sc* __restrict__ v_all, sc* __restrict__ ai1_all, sc* __restrict__ ao1_all, u32 lds_bytes, u32 wit_native) {
     if (blockIdx.x >= rng_blocks) {
-        witness_gates_block((blockIdx.x - rng_blocks) * blockDim.x, B, m, n1, n_cst, w_terms, w_loff, w_roff, cst_all, v_all, ai1_all, ao1_all, lds_bytes);
+        witness_gates_block((blockIdx.x - rng_blocks) * blockDim.x, B, m, n1, n_cst, w_terms, w_loff, w_roff, cst_all, v_all, ai1_all, ao1_all, lds_bytes, wit_native);
         return;
     }
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -543,9 +606,9 @@ __global__ void k_open_bulk8(u32 B, u32 rng_blocks, u32 n1, u32 count, merlin_tr
 // The draws go out as (even bits, odd bits) pairs; k_reduce_draws joins them (interleaved = 1).  Witness blocks as in k_open_bulk.
 __global__ void k_open_bulk50(u32 B, u32 rng_blocks, u32 n1, u32 count, merlin_transcript* __restrict__ rng, u32* __restrict__ raw, u32 m,
                               u32 n_cst, const u32* __restrict__ w_terms, const u32* __restrict__ w_loff, const u32* __restrict__ w_roff,
-                              const sc* __restrict__ cst_all, const sc* __restrict__ v_all, sc* __restrict__ ai1_all, sc* __restrict__ ao1_all, u32 lds_bytes) {
+                              const sc* __restrict__ cst_all, const sc* __restrict__ v_all, sc* __restrict__ ai1_all, sc* __restrict__ ao1_all, u32 lds_bytes, u32 wit_native) {
     if (blockIdx.x >= rng_blocks) {
-        witness_gates_block((blockIdx.x - rng_blocks) * blockDim.x, B, m, n1, n_cst, w_terms, w_loff, w_roff, cst_all, v_all, ai1_all, ao1_all, lds_bytes);
+        witness_gates_block((blockIdx.x - rng_blocks) * blockDim.x, B, m, n1, n_cst, w_terms, w_loff, w_roff, cst_all, v_all, ai1_all, ao1_all, lds_bytes, wit_native);
         return;
     }
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1315,6 +1378,10 @@ int32_t circuit_get(bbp_ctx* ctx, uint32_t n_items, const CircuitDev** out) {
         ctx->err = "circuit does not pad to 2048 multipliers";
         return BBP_ERR_GENS_LEN;
     }
+    if (c.n_mul != 4u * 4u * (u32)BBP_MIMC_ROUNDS + 3u * n_items + 2u || c.m != 4u + n_items) {  // what witness_gates_native_lane writes
+        ctx->err = "circuit synthesis and the native witness disagree about the multiplier count";
+        return BBP_ERR_INTERNAL;
+    }
     CircuitDev* d = new CircuitDev();
     d->n_items = n_items;
     d->m = c.m;
@@ -1570,17 +1637,17 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
                 if (ctx->rng_dpp >= 2) {
                     interleaved = 1;
                     LAUNCH_LDS(ctx, TAG_RNG, k_open_bulk50, nb_rng + nb_wit, cblk8, hog8, s, B, nb_rng, n1, 2 + 2 * n1, bd.rng, (u32*)ctx->raw[sidx].p, m,
-                               c.n_cst, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v, bd.ai1, bd.ao1, hog8);
+                               c.n_cst, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v, bd.ai1, bd.ao1, hog8, (u32)ctx->witness_native);
                 } else {
                     LAUNCH_LDS(ctx, TAG_RNG, k_open_bulk8, nb_rng + nb_wit, cblk8, hog8, s, B, nb_rng, n1, 2 + 2 * n1, bd.rng, (u32*)ctx->raw[sidx].p, m,
-                               c.n_cst, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v, bd.ai1, bd.ao1, hog8);
+                               c.n_cst, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v, bd.ai1, bd.ao1, hog8, (u32)ctx->witness_native);
                 }
             } else {
                 u32 hogb = 0;
                 if ((rc = serial_lds_bytes(ctx, (const void*)k_open_bulk, &hogb))) return rc;
                 const u32 nb_rng = cdiv(B * 32, cblk), nb_wit = cdiv(B, cblk);
                 LAUNCH_LDS(ctx, TAG_RNG, k_open_bulk, nb_rng + nb_wit, cblk, hogb, s, B, nb_rng, n1, 2 + 2 * n1, bd.rng, (u32*)ctx->raw[sidx].p, m,
-                           c.n_cst, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v, bd.ai1, bd.ao1, hogb);
+                           c.n_cst, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v, bd.ai1, bd.ao1, hogb, (u32)ctx->witness_native);
             }
         }
         LAUNCH(ctx, TAG_RNG, k_reduce_draws, cdiv((u32)(B * n_draws), 128), 128, s, B, n1, (const u32*)ctx->raw[sidx].p, bd.ai1, bd.ao1, bd.s1, interleaved);

@@ -384,6 +384,7 @@ def test_calls_from_different_streams_are_serialised(ctx, oc, bbp):
     {"BBP_RNG_COOP": "0"},                                      # TranscriptRng draw chain on one lane per proof (round-1 path)
     {"BBP_RNG_COOP": "1", "BBP_RNG_BLOCK": "64", "BBP_SERIAL_LDS": "0"},  # cooperative rng forced: one wavefront (two proofs) per workgroup, not fenced
     {"BBP_RNG_COOP": "1", "BBP_RNG_BLOCK": "1024"},             # cooperative rng forced: 32 proofs per reserved CU
+    {"BBP_RNG_COOP": "1", "BBP_WITNESS_NATIVE": "0"},           # ... with the gates interpreted from the compiled gadget program (default: written from the wiring itself)
     {"BBP_RNG_COOP": "1", "BBP_RNG_DPP": "1"},                  # ... one word per lane with DPP / permlane-swap theta (round 3; the default is round 4's half-word form, keccak_wave.h)
     {"BBP_RNG_COOP": "1", "BBP_RNG_DPP": "1", "BBP_RNG_BLOCK": "64", "BBP_SERIAL_LDS": "0"},
     {"BBP_RNG_COOP": "1", "BBP_RNG_DPP": "0"},                  # ... in its 25-lane ds_bpermute form (two proofs per wavefront)
