@@ -306,13 +306,13 @@ int32_t commit_launch(bbp_ctx* ctx, u32 count, const sc* values, const sc* blind
 #define BBP_ENCODE_ATTR
 #endif
 __global__ BBP_LANE_KERNEL BBP_ENCODE_ATTR void k_encode_strided(u32 count, u32 per_proof, const ge* __restrict__ pts, u32 pts_stride, u32* __restrict__ enc,
-                                 u32 enc_stride_words, u32 enc_off_words) {
+                                 u32 enc_stride_words, u32 enc_off_words, u32 pts_cstride) {
     BBP_THIN_PRIO();
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= count) return;
     u32 p = t / per_proof, c = t % per_proof;
     u32 w[8];
-    ge_encode_words(w, pts[(size_t)p * pts_stride + c]);
+    ge_encode_words(w, pts[(size_t)p * pts_stride + (size_t)c * pts_cstride]);  // point c of proof p (pts_cstride = 1: a proof's points are contiguous)
     u32* o = enc + (size_t)p * enc_stride_words + enc_off_words + 8 * c;
 #pragma unroll
     for (int i = 0; i < 8; i++) o[i] = w[i];
@@ -699,8 +699,7 @@ __global__ BBP_LANE_KERNEL void k_tr_yz(u32 B, u32 m, const u32* __restrict__ en
 // out[p][e] = base[p]^e for e in [0, count): one lane per chunk of 32 exponents
 // mont_out = 0: out[e] = x^e;  1: out[e] = x^e R (Montgomery form, for consumers that multiply by it once).  Either way one
 // Montgomery multiplication per power: cur * (x R) * R^-1 = cur * x keeps cur in whichever domain it started in.
-__global__ BBP_LANE_KERNEL void k_powers(u32 B, u32 count, const sc* __restrict__ misc, int slot, sc* __restrict__ out, u32 out_stride, u32 mont_out) {
-    BBP_THIN_PRIO();
+__device__ __forceinline__ void powers_lane(u32 B, u32 count, const sc* __restrict__ misc, int slot, sc* __restrict__ out, u32 out_stride, u32 mont_out) {
     const u32 chunks = (count + 31) / 32;
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B * chunks) return;
@@ -716,6 +715,23 @@ __global__ BBP_LANE_KERNEL void k_powers(u32 B, u32 count, const sc* __restrict_
         cur = sc_montmul(cur, xm);
     }
 }
+__global__ BBP_LANE_KERNEL void k_powers(u32 B, u32 count, const sc* __restrict__ misc, int slot, sc* __restrict__ out, u32 out_stride, u32 mont_out) {
+    BBP_THIN_PRIO();
+    powers_lane(B, count, misc, slot, out, out_stride, mont_out);
+}
+// the prover's three power tables (z^k, y^k, y^-k) in one launch: blockIdx.y picks the table (three launches of ~64 us each were
+// three dependent-chain latencies of a small call)
+struct PowersJob {
+    u32 count;
+    int slot;
+    sc* out;
+    u32 out_stride, mont_out;
+};
+__global__ BBP_LANE_KERNEL void k_powers3(u32 B, const sc* __restrict__ misc, PowersJob a, PowersJob b, PowersJob c) {
+    BBP_THIN_PRIO();
+    const PowersJob j = blockIdx.y == 0 ? a : blockIdx.y == 1 ? b : c;
+    powers_lane(B, j.count, misc, j.slot, j.out, j.out_stride, j.mont_out);
+}
 
 // K4: flattened constraint weights.  target t of proof p = sum over its entries of +-z^(q+1)
 __global__ void k_flatten(u32 B, u32 n_tgt, u32 n_mul, u32 m, const u32* __restrict__ f_off, const u32* __restrict__ f_ent,
@@ -727,10 +743,20 @@ __global__ void k_flatten(u32 B, u32 n_tgt, u32 n_mul, u32 m, const u32* __restr
     u32 p = t / n_tgt, k = t % n_tgt;
     const sc* zp = zpow + (size_t)p * zstride;
     sc acc = sc_zero();
-    for (u32 e = f_off[k]; e < f_off[k + 1]; e++) {
-        u32 w = f_ent[e];
-        sc zq = ld_sc(&zp[(w & 0x7fffffffu) + 1]);
-        acc = (w >> 31) ? sc_sub(acc, zq) : sc_add(acc, zq);
+    // eight entries at a time: their powers are fetched together (independent loads).  A handful of targets -- a MiMC key, the
+    // hash input x -- sit in several hundred constraints, and one load round trip per entry made those lanes the whole kernel
+    // (334 us for ONE proof)
+    const u32 e0 = f_off[k], e1 = f_off[k + 1];
+    for (u32 e = e0; e < e1; e += 8) {
+        u32 w[8];
+        sc zq[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) w[i] = f_ent[min(e + (u32)i, e1 - 1)];
+#pragma unroll
+        for (int i = 0; i < 8; i++) zq[i] = ld_sc(&zp[(w[i] & 0x7fffffffu) + 1]);
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            if (e + (u32)i < e1) acc = (w[i] >> 31) ? sc_sub(acc, zq[i]) : sc_add(acc, zq[i]);
     }
     sc* dst = k < n_mul ? &wl[(size_t)p * wstride + k]
               : k < 2 * n_mul ? &wr[(size_t)p * wstride + (k - n_mul)]
@@ -1607,7 +1633,7 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
         LAUNCH(ctx, TAG_WITNESS, k_witness_head, cdiv(B, 64), 64, s, B, N, c.n_cst, in_dev, bd.cst, bd.v);
         LAUNCH(ctx, TAG_TRANSCRIPT, k_load_blindings, cdiv(B * m, 64), 64, s, B, m, ent_dev, bd.vb);
         if ((rc = commit_launch(ctx, B * m, bd.v, bd.vb, m, m, m, bd.pts, m + 8, s))) return rc;
-        LAUNCH(ctx, TAG_ENCODE, k_encode_strided, cdiv(B * m, 64), 64, s, B * m, m, bd.pts, m + 8, bd.enc, encw, 0u);
+        LAUNCH(ctx, TAG_ENCODE, k_encode_strided, cdiv(B * m, 64), 64, s, B * m, m, bd.pts, m + 8, bd.enc, encw, 0u, 1u);
         // one wavefront per proof for the draw chain: always for batches up to rng_coop_below proofs; for larger ones (up to
         // rng_coop_idle_below) only when NO earlier prove call is on the device -- a lone 1024-proof call then returns after 58
         // instead of 81 ms, while a caller that keeps the device busy keeps the single-lane chain (a wavefront per proof costs a
@@ -1729,12 +1755,15 @@ static int32_t prove_heavy(bbp_ctx* ctx, const CircuitDev& c, const BatchDev& bd
     // the next slice starts once this one has issued its three commitment MSMs: its own commitment MSMs then run under this
     // slice's long MSM-free stretch (encode, transcript, powers, flatten, poly, T commitments, l/r vectors)
     if (stagger && ctx->stagger_mode == 3) BBP_HIP_TRY(ctx, hipEventRecord(stagger, s));
-    for (u32 k = 0; k < 3; k++)
-        LAUNCH(ctx, TAG_ENCODE, k_encode_strided, cdiv(B, 64), 64, s, B, 1u, tmp + (size_t)k * B, 1u, bd.enc, encw, 8 * (m + k));
+    // the three commitments of a proof in ONE launch (they sit B points apart: tmp[k * B + p]); three launches were three
+    // dependent-chain latencies (3 x 82 us for a small call)
+    LAUNCH(ctx, TAG_ENCODE, k_encode_strided, cdiv(3 * B, 64), 64, s, 3 * B, 3u, tmp, 1u, bd.enc, encw, 8 * m, B);
     LAUNCH(ctx, TAG_TRANSCRIPT, k_tr_yz, cdiv(B, 64), 64, s, B, m, bd.enc, bd.tr, bd.misc);
-    LAUNCH(ctx, TAG_POLY, k_powers, cdiv(B * cdiv(c.n_cons + 1, 32), 64), 64, s, B, c.n_cons + 1, bd.misc, (int)MS_Z, bd.zpow, c.n_cons + 1, 0u);
-    LAUNCH(ctx, TAG_POLY, k_powers, cdiv(B * cdiv(2049, 32), 64), 64, s, B, 2049u, bd.misc, (int)MS_Y, bd.ypow, 2049u, 0u);
-    LAUNCH(ctx, TAG_POLY, k_powers, cdiv(B * cdiv(2048, 32), 64), 64, s, B, 2048u, bd.misc, (int)MS_YINV, bd.yipow, 2048u, 0u);
+    {
+        const u32 widest = c.n_cons + 1 > 2049u ? c.n_cons + 1 : 2049u;
+        const PowersJob jz{c.n_cons + 1, (int)MS_Z, bd.zpow, c.n_cons + 1, 0u}, jy{2049u, (int)MS_Y, bd.ypow, 2049u, 0u}, jyi{2048u, (int)MS_YINV, bd.yipow, 2048u, 0u};
+        LAUNCH(ctx, TAG_POLY, k_powers3, dim3(cdiv(B * cdiv(widest, 32), 64), 3), 64, s, B, bd.misc, jz, jy, jyi);
+    }
     const u32 n_tgt = 3 * n1 + m;
     LAUNCH(ctx, TAG_POLY, k_flatten, cdiv(B * n_tgt, 128), 128, s, B, n_tgt, n1, m, c.f_off, c.f_ent, bd.zpow, c.n_cons + 1, bd.wl, bd.wr,
            bd.wo, bd.wv, 2048u);
@@ -1742,7 +1771,7 @@ static int32_t prove_heavy(bbp_ctx* ctx, const CircuitDev& c, const BatchDev& bd
            bd.r1, bd.r3, bd.misc);
     LAUNCH(ctx, TAG_TRANSCRIPT, k_tr_tblind, cdiv(B, 64), 64, s, B, bd.rng, bd.misc);
     LAUNCH(ctx, TAG_COMMIT, k_commit_T, cdiv(B * 5, 64), 64, s, B, bd.misc, ctx->comb, bd.pts, m + 8, m);
-    LAUNCH(ctx, TAG_ENCODE, k_encode_strided, cdiv(B * 5, 64), 64, s, B * 5, 5u, bd.pts + (m + 3), m + 8, bd.enc, encw, 8 * (m + 3));
+    LAUNCH(ctx, TAG_ENCODE, k_encode_strided, cdiv(B * 5, 64), 64, s, B * 5, 5u, bd.pts + (m + 3), m + 8, bd.enc, encw, 8 * (m + 3), 1u);
     LAUNCH(ctx, TAG_TRANSCRIPT, k_tr_ux, cdiv(B, 64), 64, s, B, m, n1, bd.enc, bd.wv, bd.vb, bd.ai1, bd.ao1, bd.s1, bd.tr, bd.misc);
     LAUNCH(ctx, TAG_POLY, k_lrvec, cdiv(B * 2048, 128), 128, s, B, n1, bd.l1, bd.r0, bd.r1, bd.r3, bd.ao1, bd.s1, bd.ypow, bd.yipow, bd.misc,
            bd.a, bd.b, bd.g, bd.h);
@@ -1752,7 +1781,7 @@ static int32_t prove_heavy(bbp_ctx* ctx, const CircuitDev& c, const BatchDev& bd
         if (r > 1) LAUNCH(ctx, TAG_TRANSCRIPT, k_ipa_challenge, cdiv(B, 64), 64, s, B, r - 1, m, bd.enc, bd.tr, bd.misc);
         LAUNCH(ctx, TAG_IPA_SCALARS, k_ipa_round, B, IPA_BLK, s, r, n1, bd.misc, bd.a, bd.b, bd.g, bd.h, bd.lr);
         if ((rc = msm_launch(ctx, 2 * B, 2049, (const u32*)bd.lr, c.idx_ipa + (size_t)(r - 1) * 2 * 2049, bd.lrpts, s, 2, slot))) return rc;
-        LAUNCH(ctx, TAG_ENCODE, k_encode_strided, cdiv(2 * B, 64), 64, s, 2 * B, 2u, bd.lrpts, 2u, bd.enc, encw, 8 * (m + 8 + 2 * (r - 1)));
+        LAUNCH(ctx, TAG_ENCODE, k_encode_strided, cdiv(2 * B, 64), 64, s, 2 * B, 2u, bd.lrpts, 2u, bd.enc, encw, 8 * (m + 8 + 2 * (r - 1)), 1u);
     }
     if (tail_from <= 11) {
         // switch to explicit folded generators: absorb round FOLD_ROUND-1, fold a, b, update g, h (no scalar rows), then one
@@ -1769,7 +1798,7 @@ static int32_t prove_heavy(bbp_ctx* ctx, const CircuitDev& c, const BatchDev& bd
             const u32 n = 1024u >> (r - 1);
             LAUNCH(ctx, TAG_VARBASE, k_tail_lr, cdiv(B, TAIL_PPB), TAIL_BLK, s, B, n, r > tail_from ? r - 1 : 0u, m, bd.enc, bd.tr, bd.misc, bd.a, bd.b, bd.g, bd.h, ftab,
                    ctx->btab, bd.lrpts);
-            LAUNCH(ctx, TAG_ENCODE, k_encode_strided, cdiv(2 * B, 64), 64, s, 2 * B, 2u, bd.lrpts, 2u, bd.enc, encw, 8 * (m + 8 + 2 * (r - 1)));
+            LAUNCH(ctx, TAG_ENCODE, k_encode_strided, cdiv(2 * B, 64), 64, s, 2 * B, 2u, bd.lrpts, 2u, bd.enc, encw, 8 * (m + 8 + 2 * (r - 1)), 1u);
         }
     }
     LAUNCH(ctx, TAG_TRANSCRIPT, k_ipa_final, cdiv(B, 64), 64, s, B, m, bd.enc, bd.tr, bd.misc, bd.a, bd.b);
