@@ -287,10 +287,88 @@ __global__ BBP_LANE_KERNEL void k_commit(u32 count, u32 per_proof, const sc* __r
     out[(size_t)p * out_stride + c] = acc;
 }
 
+// Small launches: a commitment on COMMIT_L lanes.  One lane walks 2 x 64 comb digits (~120 dependent mixed additions: 380 us for
+// ONE proof's twelve commitments, and again for its five T commitments); here lane q of a group takes the digit positions
+// j = q (mod COMMIT_L) of both scalars (every lane recodes the whole scalar -- the carries -- which is cheap) and three shuffle
+// steps add the partial sums.  The sum is the same group element, its encoding the same bytes.
+constexpr int COMMIT_L = 8;
+__device__ ge comb_mul_add_part(ge acc, const niels_packed* __restrict__ comb_base, const sc& s, u32 q) {
+    // the signed radix-16 digits of the whole scalar first (the carries are a chain): magnitudes as nibbles, signs as a bit mask;
+    // then the lane's own eight positions q, q + 8, ... -- every lane of the wavefront adds at the same time
+    u32 mags[8];
+    u64 negs = 0;
+    u32 carry = 0;
+#pragma unroll
+    for (int w = 0; w < 8; w++) {
+        u32 mw = 0;
+#pragma unroll
+        for (int n = 0; n < 8; n++) {
+            const u32 d = ((s.v[w] >> (4 * n)) & 15u) + carry;
+            carry = d > 8u;
+            mw |= (carry ? 16u - d : d) << (4 * n);
+            negs |= (u64)carry << (8 * w + n);
+        }
+        mags[w] = mw;
+    }
+#pragma unroll 1
+    for (int i = 0; i < 64 / COMMIT_L; i++) {
+        u32 mw = mags[0];
+#pragma unroll
+        for (int w = 1; w < 8; w++) mw = i == w ? mags[w] : mw;
+        const u32 j = q + (u32)COMMIT_L * (u32)i, mag = (mw >> (4 * q)) & 15u, neg = (u32)(negs >> j) & 1u;
+        if (mag) {
+            const uint4* qq = reinterpret_cast<const uint4*>(comb_base + (size_t)j * 8 + (mag - 1));
+            uint4 q0 = qq[0], q1 = qq[1], q2 = qq[2], q3 = qq[3], q4 = qq[4], q5 = qq[5];
+            ge_niels n;
+            n.ypx = BBP_FE_LIT(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w);
+            n.ymx = BBP_FE_LIT(q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w);
+            n.xy2d = BBP_FE_LIT(q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w);
+            if (neg) {
+                fe t = n.ypx;
+                n.ypx = n.ymx;
+                n.ymx = t;
+                n.xy2d = fe_neg(n.xy2d);
+            }
+            acc = ge_madd(acc, n);
+        }
+    }
+    return acc;
+}
+__device__ __forceinline__ ge commit_group_sum(ge acc) {  // lane 0 of every COMMIT_L-lane group ends up with the group's sum
+#pragma unroll 1
+    for (int d = COMMIT_L / 2; d >= 1; d >>= 1) {
+        ge other;
+        const u32* w = reinterpret_cast<const u32*>(&acc);
+        u32* o = reinterpret_cast<u32*>(&other);
+#pragma unroll
+        for (int i = 0; i < GE_WORDS; i++) o[i] = (u32)__shfl_down((int)w[i], d, 64);
+        acc = ge_add(acc, other);  // (lanes whose partner lies in the next group add something nobody reads)
+    }
+    return acc;
+}
+__global__ BBP_LANE_KERNEL void k_commit_split(u32 count, u32 per_proof, const sc* __restrict__ values, const sc* __restrict__ blindings, u32 stride_v,
+                                               u32 stride_b, const niels_packed* __restrict__ comb, ge* __restrict__ out, u32 out_stride) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x, g = t / COMMIT_L, q = t % COMMIT_L;
+    const u32 gi = g < count ? g : count - 1;  // whole wavefronts reach the shuffles
+    const u32 p = gi / per_proof, c = gi % per_proof;
+    const sc v = ld_sc(&values[(size_t)p * stride_v + c]);
+    const sc b = ld_sc(&blindings[(size_t)p * stride_b + c]);
+    ge acc = comb_mul_add_part(ge_identity(), comb, v, q);
+    acc = comb_mul_add_part(acc, comb + 64 * 8, b, q);
+    acc = commit_group_sum(acc);
+    if (q == 0 && g < count) out[(size_t)p * out_stride + c] = acc;
+}
+
 int32_t commit_launch(bbp_ctx* ctx, u32 count, const sc* values, const sc* blindings, u32 stride_v, u32 stride_b, u32 per_proof,
                       ge* out, u32 out_stride, hipStream_t s) {
     if (!count) return BBP_OK;
     ScopedEvent ev(ctx, TAG_COMMIT, s);
+    if (count <= (u32)ctx->commit_split_below) {
+        hipLaunchKernelGGL(k_commit_split, dim3((count * COMMIT_L + 63) / 64), dim3(64), 0, s, count, per_proof, values, blindings, stride_v, stride_b,
+                           ctx->comb, out, out_stride);
+        BBP_HIP_TRY(ctx, hipGetLastError());
+        return BBP_OK;
+    }
     hipLaunchKernelGGL(k_commit, dim3((count + 63) / 64), dim3(64), 0, s, count, per_proof, values, blindings, stride_v, stride_b,
                        ctx->comb, out, out_stride);
     BBP_HIP_TRY(ctx, hipGetLastError());
@@ -852,6 +930,18 @@ __global__ BBP_LANE_KERNEL void k_tr_tblind(u32 B, merlin_transcript* __restrict
 }
 
 // T_k = t_k B + tb_k B~ for k in {1,3,4,5,6}: one lane per (proof, k)
+__global__ BBP_LANE_KERNEL void k_commit_T_split(u32 B, const sc* __restrict__ misc, const niels_packed* __restrict__ comb, ge* __restrict__ pts, u32 pts_stride, u32 m) {
+    BBP_THIN_PRIO();
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x, g = t / COMMIT_L, q = t % COMMIT_L;
+    const u32 gi = g < B * 5 ? g : B * 5 - 1;
+    const u32 p = gi / 5, k = gi % 5;
+    const int slot[5] = {0, 2, 3, 4, 5};
+    const sc* ms = misc + (size_t)p * MS_COUNT;
+    ge acc = comb_mul_add_part(ge_identity(), comb, ld_sc(&ms[MS_T1 + slot[k]]), q);
+    acc = comb_mul_add_part(acc, comb + 64 * 8, ld_sc(&ms[MS_TB1 + slot[k]]), q);
+    acc = commit_group_sum(acc);
+    if (q == 0 && g < B * 5) pts[(size_t)p * pts_stride + m + 3 + k] = acc;
+}
 __global__ BBP_LANE_KERNEL void k_commit_T(u32 B, const sc* __restrict__ misc, const niels_packed* __restrict__ comb, ge* __restrict__ pts, u32 pts_stride, u32 m) {
     BBP_THIN_PRIO();
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1770,7 +1860,10 @@ static int32_t prove_heavy(bbp_ctx* ctx, const CircuitDev& c, const BatchDev& bd
     LAUNCH(ctx, TAG_POLY, k_poly, B, POLY_BLK, s, n1, bd.ai1, bd.ao1, bd.s1, bd.wl, bd.wr, bd.wo, 2048u, bd.ypow, bd.yipow, bd.l1, bd.r0,
            bd.r1, bd.r3, bd.misc);
     LAUNCH(ctx, TAG_TRANSCRIPT, k_tr_tblind, cdiv(B, 64), 64, s, B, bd.rng, bd.misc);
-    LAUNCH(ctx, TAG_COMMIT, k_commit_T, cdiv(B * 5, 64), 64, s, B, bd.misc, ctx->comb, bd.pts, m + 8, m);
+    if (B * 5 <= (u32)ctx->commit_split_below)
+        LAUNCH(ctx, TAG_COMMIT, k_commit_T_split, cdiv(B * 5 * COMMIT_L, 64), 64, s, B, bd.misc, ctx->comb, bd.pts, m + 8, m);
+    else
+        LAUNCH(ctx, TAG_COMMIT, k_commit_T, cdiv(B * 5, 64), 64, s, B, bd.misc, ctx->comb, bd.pts, m + 8, m);
     LAUNCH(ctx, TAG_ENCODE, k_encode_strided, cdiv(B * 5, 64), 64, s, B * 5, 5u, bd.pts + (m + 3), m + 8, bd.enc, encw, 8 * (m + 3), 1u);
     LAUNCH(ctx, TAG_TRANSCRIPT, k_tr_ux, cdiv(B, 64), 64, s, B, m, n1, bd.enc, bd.wv, bd.vb, bd.ai1, bd.ao1, bd.s1, bd.tr, bd.misc);
     LAUNCH(ctx, TAG_POLY, k_lrvec, cdiv(B * 2048, 128), 128, s, B, n1, bd.l1, bd.r0, bd.r1, bd.r3, bd.ao1, bd.s1, bd.ypow, bd.yipow, bd.misc,

@@ -423,21 +423,23 @@ def test_engine_schedules_give_identical_bytes(bbp, oc, knobs):
         c2.close()
 
 
-@pytest.mark.parametrize("small", ["1", "0"])
-def test_split_msm_geometries_give_identical_bytes(bbp, oc, small):
-    """Launches of fewer than 128 MSMs are cut into sub-MSMs; those use 128 buckets and width-9 digits (msm.hip msm_geom<2>) or,
-    BBP_MSM_SMALL=0, the 1024 buckets of the unsplit kernels.  Either way the records are the C oracle's, for one proof (sixteen
-    sub-MSMs per MSM) and for a batch that is cut in fewer pieces."""
+@pytest.mark.parametrize("knob,value", [("BBP_MSM_SMALL", "1"), ("BBP_MSM_SMALL", "0"), ("BBP_COMMIT_SPLIT_BELOW", "0"), ("BBP_WITNESS_NATIVE", "0")])
+def test_small_call_paths_give_identical_bytes(bbp, oc, knob, value):
+    """What only small launches take.  Launches of fewer than 128 MSMs are cut into sub-MSMs; those use 128 buckets and width-9
+    digits (msm.hip msm_geom<2>) or, BBP_MSM_SMALL=0, the 1024 buckets of the unsplit kernels.  Pedersen-commitment launches of
+    at most 1024 commitments put each on eight lanes (BBP_COMMIT_SPLIT_BELOW=0: one lane).  The cooperative opening launches write
+    the gates from the gadget wiring (BBP_WITNESS_NATIVE=0: interpreted).  Every way the records are the C oracle's, for one proof
+    (sixteen sub-MSMs per MSM) and for batches that are cut in fewer pieces."""
     import os
-    old = os.environ.get("BBP_MSM_SMALL")
-    os.environ["BBP_MSM_SMALL"] = small
+    old = os.environ.get(knob)
+    os.environ[knob] = value
     try:
         c2 = bbp.Context(0)
     finally:
         if old is None:
-            os.environ.pop("BBP_MSM_SMALL", None)
+            os.environ.pop(knob, None)
         else:
-            os.environ["BBP_MSM_SMALL"] = old
+            os.environ[knob] = old
     try:
         for B, N, seed in ((1, 8, 77), (23, 3, 78), (100, 1, 79)):
             ins, ents, vins = _synth_batch(c2, B, N, seed=seed)
