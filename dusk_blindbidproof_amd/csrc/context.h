@@ -133,6 +133,7 @@ struct bbp_ctx {
     // of at most rng_coop_below proofs (768; with four wavefronts per CU a 512-proof chain takes ~15 ms on 64 CUs).  BBP_RNG_COOP=0 / 1 forces, BBP_RNG_COOP_BELOW, BBP_RNG_BLOCK tune.
     int rng_coop = -1;
     int rng_coop_below = 768;
+    int ipa_wide_below = 32;         // launches of at most this many proofs run k_ipa_round on 1024 lanes per proof instead of 256 (BBP_IPA_WIDE_BELOW, 0 = never)
     int commit_split_below = 1024;   // Pedersen-commitment launches of at most this many commitments put each on eight lanes (prover.hip k_commit_split; BBP_COMMIT_SPLIT_BELOW, 0 = never)
     int witness_native = 1;          // the witness blocks of the cooperative opening launches write the gates from the gadget wiring itself instead of interpreting the compiled program (BBP_WITNESS_NATIVE=0)
     int msm_small = 1;               // split MSMs (launches of fewer than 128) use width-9 digits and 128 buckets (msm.hip msm_geom<2>); BBP_MSM_SMALL=0: 1024 like the others

@@ -624,11 +624,16 @@ __global__ __launch_bounds__(MSM_T) void k_msm_fold(const u32* __restrict__ curs
 
     // D2. running-sum fold over this lane's G buckets (high to low), all lanes in lockstep
     ge running = ge_identity(), total = ge_identity();
+    if constexpr (G == 1) {  // one bucket per lane: nothing to run over (two additions to the identity were 13 us of a 122 us fold)
+        if (cursor[tid + 1] != cursor[tid]) running = bsum[tid];
+        total = running;
+    } else {
 #pragma unroll 1
-    for (int r = G; r >= 1; r--) {
-        const u32 k = tid * G + r;
-        if (cursor[k] != cursor[k - 1]) running = ge_add(running, bsum[k - 1]);
-        total = ge_add(total, running);
+        for (int r = G; r >= 1; r--) {
+            const u32 k = tid * G + r;
+            if (cursor[k] != cursor[k - 1]) running = ge_add(running, bsum[k - 1]);
+            total = ge_add(total, running);
+        }
     }
 
     if constexpr (MODE != 1) {

@@ -1049,11 +1049,12 @@ __global__ BBP_LANE_KERNEL void k_ipa_challenge(u32 B, u32 prev_round, u32 m, co
 // K6: one inner-product round.  n = half length of THIS round (1024 >> (round-1)).
 //   round > 1: with u, 1/u of the previous round (k_ipa_challenge) fold a, b and update the factor vectors g, h.
 //   then: c_L, c_R and the scalars of this round's L and R over the ORIGINAL generators.
-constexpr int IPA_BLK = 256;
-__global__ __launch_bounds__(IPA_BLK) void k_ipa_round(u32 round, u32 n1, sc* __restrict__ misc, sc* __restrict__ a_all, sc* __restrict__ b_all,
+constexpr int IPA_BLK = 256, IPA_BLK_WIDE = 1024;  // lanes per proof: 256, or 1024 for launches of a few proofs (eight elements per lane are a 75 us chain, eleven times per proof)
+template <int BLK>
+__global__ __launch_bounds__(BLK) void k_ipa_round(u32 round, u32 n1, sc* __restrict__ misc, sc* __restrict__ a_all, sc* __restrict__ b_all,
                                                         sc* __restrict__ g_all, sc* __restrict__ h_all, sc* __restrict__ lr_all) {
     BBP_THIN_PRIO();
-    __shared__ u32 lds[2 * 8 * IPA_BLK];
+    __shared__ u32 lds[2 * 8 * BLK];
     const u32 p = blockIdx.x, tid = threadIdx.x;
     sc* ms = misc + (size_t)p * MS_COUNT;
     sc *a = a_all + (size_t)p * 2048, *b = b_all + (size_t)p * 2048, *g = g_all + (size_t)p * 2048, *h = h_all + (size_t)p * 2048;
@@ -1065,7 +1066,7 @@ __global__ __launch_bounds__(IPA_BLK) void k_ipa_round(u32 round, u32 n1, sc* __
         const sc u = sc_to_mont(ld_sc(&ms[MS_UJ])), ui = sc_to_mont(ld_sc(&ms[MS_UJI]));
         const u32 n2 = 2 * n;  // half length of the previous round = current full length
         // fold a, b: a'[i] = a[i] u + u^-1 a[n2+i] ; b'[i] = b[i] u^-1 + u b[n2+i]
-        for (u32 i = tid; i < n2; i += IPA_BLK) {
+        for (u32 i = tid; i < n2; i += BLK) {
             sc alo = ld_sc(&a[i]), ahi = ld_sc(&a[n2 + i]), blo = ld_sc(&b[i]), bhi = ld_sc(&b[n2 + i]);
             st_sc(&a[i], sc_add(sc_montmul(alo, u), sc_montmul(ui, ahi)));
             st_sc(&b[i], sc_add(sc_montmul(blo, ui), sc_montmul(u, bhi)));
@@ -1073,7 +1074,7 @@ __global__ __launch_bounds__(IPA_BLK) void k_ipa_round(u32 round, u32 n1, sc* __
         // generator factors (Montgomery form in, Montgomery form out): low half of each 2*n2 block took u^-1 (G) / u (H); high
         // half the opposite.  The tail preparation call hands them to the generator-fold MSM, which needs plain scalars.
         const bool to_plain = lr_all == nullptr;
-        for (u32 k = tid; k < 2048; k += IPA_BLK) {
+        for (u32 k = tid; k < 2048; k += BLK) {
             bool hi = (k & (2 * n2 - 1)) >= n2;
             sc gk = sc_montmul(ld_sc(&g[k]), hi ? u : ui), hk = sc_montmul(ld_sc(&h[k]), hi ? ui : u);
             st_sc(&g[k], to_plain ? sc_from_mont(gk) : gk);
@@ -1086,7 +1087,7 @@ __global__ __launch_bounds__(IPA_BLK) void k_ipa_round(u32 round, u32 n1, sc* __
     sc* L = lr_all + (size_t)p * 2 * 2049;
     sc* R = L + 2049;
     sc c[2] = {sc_zero(), sc_zero()};
-    for (u32 k = tid; k < 2048; k += IPA_BLK) {
+    for (u32 k = tid; k < 2048; k += BLK) {
         const u32 i = k & (2 * n - 1), blk = k / (2 * n);
         const bool hi = i >= n;
         const u32 io = hi ? i - n : i, rank = blk * n + io;
@@ -1102,12 +1103,12 @@ __global__ __launch_bounds__(IPA_BLK) void k_ipa_round(u32 round, u32 n1, sc* __
             st_sc(&L[1024 + rank], dup ? sc_zero() : sc_montmul(ld_sc(&b[n + io]), hk));
         }
     }
-    for (u32 i = tid; i < n; i += IPA_BLK) {
+    for (u32 i = tid; i < n; i += BLK) {
         sc alo = ld_sc(&a[i]), ahi = ld_sc(&a[n + i]), blo = ld_sc(&b[i]), bhi = ld_sc(&b[n + i]);
         c[0] = sc_add(c[0], sc_montmul(alo, bhi));  // sums of x y R^-1: one conversion after the block sum
         c[1] = sc_add(c[1], sc_montmul(ahi, blo));
     }
-    block_sum_sc<2, IPA_BLK>(c, lds);
+    block_sum_sc<2, BLK>(c, lds);
     if (tid == 0) {
         const sc wr = sc_montmul(sc_to_mont(ld_sc(&ms[MS_W])), sc_rr());  // w R^2: (c R^-1) * (w R^2) * R^-1 = c w.  Q = w B, c * Q = (c w) B
         st_sc(&L[2048], sc_montmul(c[0], wr));
@@ -1872,7 +1873,10 @@ static int32_t prove_heavy(bbp_ctx* ctx, const CircuitDev& c, const BatchDev& bd
     const u32 tail_from = B < (u32)(ctx->tail_small_below > 0 ? ctx->tail_small_below : 0) ? 12u : (u32)ctx->tail_round;
     for (u32 r = 1; r <= 11 && r < tail_from; r++) {
         if (r > 1) LAUNCH(ctx, TAG_TRANSCRIPT, k_ipa_challenge, cdiv(B, 64), 64, s, B, r - 1, m, bd.enc, bd.tr, bd.misc);
-        LAUNCH(ctx, TAG_IPA_SCALARS, k_ipa_round, B, IPA_BLK, s, r, n1, bd.misc, bd.a, bd.b, bd.g, bd.h, bd.lr);
+        if (B <= (u32)ctx->ipa_wide_below)
+            LAUNCH(ctx, TAG_IPA_SCALARS, k_ipa_round<IPA_BLK_WIDE>, B, IPA_BLK_WIDE, s, r, n1, bd.misc, bd.a, bd.b, bd.g, bd.h, bd.lr);
+        else
+            LAUNCH(ctx, TAG_IPA_SCALARS, k_ipa_round<IPA_BLK>, B, IPA_BLK, s, r, n1, bd.misc, bd.a, bd.b, bd.g, bd.h, bd.lr);
         if ((rc = msm_launch(ctx, 2 * B, 2049, (const u32*)bd.lr, c.idx_ipa + (size_t)(r - 1) * 2 * 2049, bd.lrpts, s, 2, slot))) return rc;
         LAUNCH(ctx, TAG_ENCODE, k_encode_strided, cdiv(2 * B, 64), 64, s, 2 * B, 2u, bd.lrpts, 2u, bd.enc, encw, 8 * (m + 8 + 2 * (r - 1)), 1u);
     }
@@ -1883,7 +1887,7 @@ static int32_t prove_heavy(bbp_ctx* ctx, const CircuitDev& c, const BatchDev& bd
         if ((rc = dev_reserve(ctx, vt, (size_t)B * 2 * FOLD_CLS * TAIL_TAB * sizeof(ge)))) return rc;
         ge* ftab = static_cast<ge*>(vt.p);
         LAUNCH(ctx, TAG_TRANSCRIPT, k_ipa_challenge, cdiv(B, 64), 64, s, B, tail_from - 1, m, bd.enc, bd.tr, bd.misc);
-        LAUNCH(ctx, TAG_IPA_SCALARS, k_ipa_round, B, IPA_BLK, s, tail_from, n1, bd.misc, bd.a, bd.b, bd.g, bd.h, (sc*)nullptr);
+        LAUNCH(ctx, TAG_IPA_SCALARS, k_ipa_round<IPA_BLK>, B, IPA_BLK, s, tail_from, n1, bd.misc, bd.a, bd.b, bd.g, bd.h, (sc*)nullptr);
         if ((rc = fold_generators_launch(ctx, B, bd.g, bd.h, bd.fpts, s, slot))) return rc;
         LAUNCH(ctx, TAG_VARBASE, k_tail_init, cdiv(B * FOLD_CLS, 64), 64, s, B, bd.g, bd.h);
         LAUNCH(ctx, TAG_VARBASE, k_tail_tables, cdiv(B * 2 * FOLD_CLS, 64), 64, s, B * 2 * FOLD_CLS, bd.fpts, ftab);

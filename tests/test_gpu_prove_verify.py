@@ -423,7 +423,7 @@ def test_engine_schedules_give_identical_bytes(bbp, oc, knobs):
         c2.close()
 
 
-@pytest.mark.parametrize("knob,value", [("BBP_MSM_SMALL", "1"), ("BBP_MSM_SMALL", "0"), ("BBP_COMMIT_SPLIT_BELOW", "0"), ("BBP_WITNESS_NATIVE", "0")])
+@pytest.mark.parametrize("knob,value", [("BBP_MSM_SMALL", "1"), ("BBP_MSM_SMALL", "0"), ("BBP_COMMIT_SPLIT_BELOW", "0"), ("BBP_WITNESS_NATIVE", "0"), ("BBP_IPA_WIDE_BELOW", "0")])
 def test_small_call_paths_give_identical_bytes(bbp, oc, knob, value):
     """What only small launches take.  Launches of fewer than 128 MSMs are cut into sub-MSMs; those use 128 buckets and width-9
     digits (msm.hip msm_geom<2>) or, BBP_MSM_SMALL=0, the 1024 buckets of the unsplit kernels.  Pedersen-commitment launches of
