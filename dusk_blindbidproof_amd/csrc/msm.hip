@@ -17,13 +17,15 @@
 //     B. exclusive scan -> bucket offsets
 //     C. counting-sort scatter of (row index, sign) into the MSM's HBM scratch slice (staged through an LDS image and written out
 //        as full lines for MSMs of at most 3000 terms); bucket end offsets to HBM
-//   k_msm_acc            (256 fat lanes, 156 registers, two waves per SIMD)
+//   k_msm_acc            (256 fat lanes, 151 registers, two waves per SIMD)
 //     D1. the sorted entry array is cut into 256 equal chunks, one per lane: mixed additions of gathered table rows into bucket
 //         sums (HBM); a chunk that starts inside a bucket parks its leading partial sum
 //   k_msm_fold_half / k_msm_fold  (half a wavefront per MSM for launches of >= 512 MSMs, else 128 lanes)
 //     P.  chunk-leading partials into their buckets
 //     D2. running-sum fold over the lane's buckets
 //     E.  cross-lane fold (shuffles): W = sum_k k S_k and S = sum_k S_k; result = sum_k (2k - 1) S_k = 2 W - S
+// A launch of fewer than 128 MSMs cuts each into sub-MSMs (msm_split) that take the same three kernels in their small geometry
+// (msm_geom<2>: width-9 digits, 128 buckets, one bucket per fold lane); k_msm_reduce sums the partial results.
 #include "context.h"
 
 namespace bbp {

@@ -4,6 +4,8 @@
 //
 // Pipeline (every stage is a device kernel over the batch; the host only sequences launches):
 //   k_witness_head / k_open_serial: constants + committed values; one lane per proof interprets the gadget program   (K3)
+//                  (batches on the cooperative draw chain: k_open_bulk50 -- one wavefront per sponge, keccak_wave.h -- with the
+//                  gates written from the gadget wiring beside it, witness_gates_native_lane)
 //   k_commit       V_i = v_i B + vb_i B~ through the radix-16 comb of the two Pedersen bases                (K2)
 //   k_open_serial  Merlin: "V" x m, "m"; TranscriptRng keyed with the blindings; draws i~,o~,s~,s_L,s_R     (K7)
 //   MSM x3         A_I1, A_O1, S1 (msm.hip: k_msm_sort + k_msm_acc)                                            (K1)
