@@ -133,6 +133,7 @@ struct bbp_ctx {
     // of at most rng_coop_below proofs (768; with four wavefronts per CU a 512-proof chain takes ~15 ms on 64 CUs).  BBP_RNG_COOP=0 / 1 forces, BBP_RNG_COOP_BELOW, BBP_RNG_BLOCK tune.
     int rng_coop = -1;
     int rng_coop_below = 768;
+    int tr_wave_below = 32;          // launches of at most this many proofs run the transcript kernels with one proof per wavefront and the permutations spread over its lanes (BBP_TR_WAVE_BELOW, 0 = never)
     int ipa_wide_below = 32;         // launches of at most this many proofs run k_ipa_round on 1024 lanes per proof instead of 256 (BBP_IPA_WIDE_BELOW, 0 = never)
     int commit_split_below = 1024;   // Pedersen-commitment launches of at most this many commitments put each on eight lanes (prover.hip k_commit_split; BBP_COMMIT_SPLIT_BELOW, 0 = never)
     int witness_native = 1;          // the witness blocks of the cooperative opening launches write the gates from the gadget wiring itself instead of interpreting the compiled program (BBP_WITNESS_NATIVE=0)

@@ -80,8 +80,13 @@ BBP_HD_NOINLINE void keccak_f1600(u64* s) { keccak_f1600_body(s); }
 // ---- STROBE-128 (rate 166) -------------------------------------------------------------------------
 struct merlin_transcript {
     u64 st[25];
-    u32 pos, pos_begin, cur_flags, _pad;
+    u32 pos, pos_begin, cur_flags;
+    u32 wave;  // device, prover.hip only: all 64 lanes of the wavefront hold THIS transcript and run it in lockstep; the permutation is then
+               // spread over them (keccak_wave.h keccak_f1600_wave: 2.4 us instead of 15).  Set by the kernel after loading, meaningless in memory.
 };
+#if defined(__HIP_DEVICE_COMPILE__) && defined(BBP_KECCAK_WAVE)
+__device__ void keccak_f1600_wave(u64* s);  // keccak_wave.h
+#endif
 
 #define BBP_STROBE_R 166u
 #define BBP_FLAG_I 1u
@@ -101,7 +106,11 @@ BBP_HD void strobe_run_f(merlin_transcript& t) {
     strobe_xor_byte(t, t.pos, t.pos_begin);
     strobe_xor_byte(t, t.pos + 1, 0x04);
     strobe_xor_byte(t, BBP_STROBE_R + 1, 0x80);
-    keccak_f1600(t.st);
+#if defined(__HIP_DEVICE_COMPILE__) && defined(BBP_KECCAK_WAVE)
+    if (t.wave) keccak_f1600_wave(t.st);
+    else
+#endif
+        keccak_f1600(t.st);
     t.pos = 0;
     t.pos_begin = 0;
 }
@@ -181,7 +190,7 @@ BBP_HD void merlin_init(merlin_transcript& t, const uint8_t* label, u32 llen) {
     const uint8_t hdr[18] = {1, 168, 1, 0, 1, 96, 'S', 'T', 'R', 'O', 'B', 'E', 'v', '1', '.', '0', '.', '2'};
     for (u32 i = 0; i < 18; i++) strobe_xor_byte(t, i, hdr[i]);
     keccak_f1600(t.st);
-    t.pos = t.pos_begin = t.cur_flags = t._pad = 0;
+    t.pos = t.pos_begin = t.cur_flags = t.wave = 0;
     const uint8_t proto[11] = {'M', 'e', 'r', 'l', 'i', 'n', ' ', 'v', '1', '.', '0'};
     strobe_meta_ad(t, proto, 11, false);
     const uint8_t ds[7] = {'d', 'o', 'm', '-', 's', 'e', 'p'};

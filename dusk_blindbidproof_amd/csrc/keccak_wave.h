@@ -170,6 +170,32 @@ __device__ __forceinline__ u32 kw_keccak_f(u32 a, const kw_lane& c, const kw_iot
     kw_rounds8(a, k.v + 16, k.cp + 16, c);
     return a ^ k.v[24];
 }
+#if defined(BBP_KECCAK_WAVE)
+// The permutation of ONE transcript that all 64 lanes of a wavefront hold in lockstep (merlin_transcript::wave; the transcript kernels of
+// small launches, prover.hip): the state goes through a 200-byte LDS slot per wavefront -- lane 0 writes its 25 words, every lane picks
+// its half-word, the rounds run as in the draw chain, the even-half lanes write the joined words back and every lane reads all 25.
+// ~2.4 us instead of 15 for the one-lane permutation.  Must be reached by the whole wavefront (uniform control flow).
+__device__ __noinline__ void keccak_f1600_wave(u64* s) {
+    __shared__ u64 kx[16][25];  // per wavefront of the workgroup (at most 1024 lanes)
+    const u32 L = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    if (L == 0) {
+#pragma unroll
+        for (int i = 0; i < 25; i++) kx[w][i] = s[i];
+    }
+    __syncthreads();
+    const kw_lane c = kw_setup(L);
+    const kw_iota k = kw_iota_setup(L);
+    u32 a = c.live ? kw_half(kx[w][c.word], c.half) : 0u;
+    __syncthreads();
+    a = kw_keccak_f(a, c, k);
+    const auto q = __builtin_amdgcn_permlane32_swap(a, a, false, false);  // the odd halves, for the lanes of the even ones
+    if (c.live && c.lower) kx[w][c.word] = kw_join(a, q[1]);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 25; i++) s[i] = kx[w][i];
+    __syncthreads();
+}
+#endif
 #endif
 
 }  // namespace bbp

@@ -23,6 +23,8 @@
 // over the ORIGINAL resident generators with scalars a[i] * g[k] / b[i] * h[k], where g[k], h[k] accumulate the
 // challenge products u_r^(+-1) that the reference applies by folding G and H (A.6).  The group elements are equal,
 // encodings are canonical, hence identical bytes -- and every MSM of the prover is a fixed-base MSM over one table.
+// the transcript kernels of small launches run one transcript per WAVEFRONT and spread its permutations over the lanes (keccak.h strobe_run_f)
+#define BBP_KECCAK_WAVE 1
 #include <string.h>
 
 #include "batch.h"
@@ -406,8 +408,9 @@ __device__ __forceinline__ u32 enc_stride_words(u32 m) { return (m + 8 + 22) * 8
 
 __device__ void tr_open_lane(u32 p, u32 m, u32 n1, const merlin_transcript& prefix, const u32* __restrict__ enc, const u8* __restrict__ entropy,
                              const sc* __restrict__ vb_all, u32* __restrict__ raw, merlin_transcript* __restrict__ tr_out,
-                             merlin_transcript* __restrict__ rng_out, bool coop) {
+                             merlin_transcript* __restrict__ rng_out, bool coop, u32 wave) {
     merlin_transcript t = prefix;  // Transcript::new(b"BlindBidProofGadget") + r1cs_domain_sep (A.4)
+    t.wave = wave;
     const u32* e = enc + (size_t)p * enc_stride_words(m);
     for (u32 i = 0; i < m; i++) tr_append_words(t, LBL("V"), e + 8 * i);
     merlin_append_u64(t, LBL("m"), (u64)m);
@@ -433,6 +436,7 @@ __device__ void tr_open_lane(u32 p, u32 m, u32 n1, const merlin_transcript& pref
     }
     // the remaining 2 + 2 n1 draws: BBP_RNG_COOP (default) leaves them to the cooperative kernel (k_open_bulk, 25 lanes per sponge)
     if (!coop) merlin_rng_fill64_bulk(r, 2 + 2 * n1, rw + 16);
+    t.wave = r.wave = 0;  // (memory never holds the flag: every kernel sets it for itself)
     tr_out[p] = t;
     rng_out[p] = r;
 }
@@ -449,8 +453,10 @@ __global__ void k_open_serial(u32 B, u32 rng_blocks, u32 m, u32 n1, merlin_trans
                               const sc* __restrict__ cst_all, const sc* __restrict__ v_all, sc* __restrict__ ai1_all, sc* __restrict__ ao1_all,
                               u32 coop) {
     if (blockIdx.x < rng_blocks) {
-        const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
-        if (p < B) tr_open_lane(p, m, n1, prefix, enc, entropy, vb_all, raw, tr_out, rng_out, coop != 0);
+        // coop: 0 = the whole draw chain here; 1 = the transcript prefix and the first draw only (the chain follows in k_open_bulk*);
+        // 2 = the same with one proof per WAVEFRONT, every lane in lockstep, the permutations spread over the lanes
+        const u32 t = blockIdx.x * blockDim.x + threadIdx.x, p = coop == 2 ? t >> 6 : t;
+        if (p < B) tr_open_lane(p, m, n1, prefix, enc, entropy, vb_all, raw, tr_out, rng_out, coop != 0, coop == 2);
     } else {
         const u32 p = (blockIdx.x - rng_blocks) * blockDim.x + threadIdx.x;
         if (p < B) witness_gates_lane(p, m, n1, n_cst, w_terms, w_loff, w_roff, cst_all, v_all, ai1_all, ao1_all);
@@ -753,11 +759,13 @@ __global__ void k_load_blindings(u32 B, u32 m, const u8* __restrict__ entropy, s
     st_sc(&vb_all[(size_t)p * m + i], sc_reduce256(w));
 }
 
-__global__ BBP_LANE_KERNEL void k_tr_yz(u32 B, u32 m, const u32* __restrict__ enc, merlin_transcript* __restrict__ tr, sc* __restrict__ misc) {
+__global__ BBP_LANE_KERNEL void k_tr_yz(u32 B, u32 m, const u32* __restrict__ enc, merlin_transcript* __restrict__ tr, sc* __restrict__ misc, u32 wave) {
     BBP_THIN_PRIO();
     u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (wave) p >>= 6;  // one transcript per wavefront, every lane in lockstep (keccak_wave.h keccak_f1600_wave)
     if (p >= B) return;
     merlin_transcript t = tr[p];
+    t.wave = wave;
     const u32* e = enc + (size_t)p * enc_stride_words(m) + 8 * m;
     tr_append_words(t, LBL("A_I1"), e);
     tr_append_words(t, LBL("A_O1"), e + 8);
@@ -773,6 +781,7 @@ __global__ BBP_LANE_KERNEL void k_tr_yz(u32 B, u32 m, const u32* __restrict__ en
     st_sc(&ms[MS_Y], y);
     st_sc(&ms[MS_Z], z);
     st_sc(&ms[MS_YINV], sc_invert(y));
+    t.wave = 0;  // (memory never holds the flag: every kernel sets it for itself)
     tr[p] = t;
 }
 
@@ -917,17 +926,20 @@ __global__ __launch_bounds__(POLY_BLK) void k_poly(u32 n1, const sc* __restrict_
     }
 }
 
-__global__ BBP_LANE_KERNEL void k_tr_tblind(u32 B, merlin_transcript* __restrict__ rng, sc* __restrict__ misc) {
+__global__ BBP_LANE_KERNEL void k_tr_tblind(u32 B, merlin_transcript* __restrict__ rng, sc* __restrict__ misc, u32 wave) {
     BBP_THIN_PRIO();
     u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (wave) p >>= 6;  // one transcript per wavefront, every lane in lockstep (keccak_wave.h keccak_f1600_wave)
     if (p >= B) return;
     merlin_transcript r = rng[p];
+    r.wave = wave;
     sc* ms = misc + (size_t)p * MS_COUNT;
     st_sc(&ms[MS_TB1], rng_scalar(r));  // t_1, t_3, t_4, t_5, t_6 blindings, in this order (A.5 step 10)
     st_sc(&ms[MS_TB3], rng_scalar(r));
     st_sc(&ms[MS_TB4], rng_scalar(r));
     st_sc(&ms[MS_TB5], rng_scalar(r));
     st_sc(&ms[MS_TB6], rng_scalar(r));
+    r.wave = 0;  // (memory never holds the flag: every kernel sets it for itself)
     rng[p] = r;
 }
 
@@ -958,11 +970,13 @@ __global__ BBP_LANE_KERNEL void k_commit_T(u32 B, const sc* __restrict__ misc, c
 
 __global__ BBP_LANE_KERNEL void k_tr_ux(u32 B, u32 m, u32 n1, const u32* __restrict__ enc, const sc* __restrict__ wv, const sc* __restrict__ vb,
                         const sc* __restrict__ ai1, const sc* __restrict__ ao1, const sc* __restrict__ s1,
-                        merlin_transcript* __restrict__ tr, sc* __restrict__ misc) {
+                        merlin_transcript* __restrict__ tr, sc* __restrict__ misc, u32 wave) {
     BBP_THIN_PRIO();
     u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (wave) p >>= 6;  // one transcript per wavefront, every lane in lockstep (keccak_wave.h keccak_f1600_wave)
     if (p >= B) return;
     merlin_transcript t = tr[p];
+    t.wave = wave;
     const u32* e = enc + (size_t)p * enc_stride_words(m) + 8 * (m + 3);
     tr_append_words(t, LBL("T_1"), e);
     tr_append_words(t, LBL("T_3"), e + 8);
@@ -996,6 +1010,7 @@ __global__ BBP_LANE_KERNEL void k_tr_ux(u32 B, u32 m, u32 n1, const u32* __restr
     st_sc(&ms[MS_TX], t_x);
     st_sc(&ms[MS_TXB], t_xb);
     st_sc(&ms[MS_EBL], e_bl);
+    t.wave = 0;  // (memory never holds the flag: every kernel sets it for itself)
     tr[p] = t;
 }
 
@@ -1033,11 +1048,13 @@ __global__ void k_lrvec(u32 B, u32 n1, const sc* __restrict__ l1, const sc* __re
 
 // Fiat-Shamir step between IPA rounds: absorb L_j, R_j (j = prev_round), draw u_j, invert it.  One lane per proof.
 __global__ BBP_LANE_KERNEL void k_ipa_challenge(u32 B, u32 prev_round, u32 m, const u32* __restrict__ enc, merlin_transcript* __restrict__ tr,
-                                sc* __restrict__ misc) {
+                                sc* __restrict__ misc, u32 wave) {
     BBP_THIN_PRIO();
     u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (wave) p >>= 6;  // one transcript per wavefront, every lane in lockstep (keccak_wave.h keccak_f1600_wave)
     if (p >= B) return;
     merlin_transcript t = tr[p];
+    t.wave = wave;
     const u32* e = enc + (size_t)p * enc_stride_words(m) + 8 * (m + 8) + 16 * (prev_round - 1);
     tr_append_words(t, LBL("L"), e);
     tr_append_words(t, LBL("R"), e + 8);
@@ -1045,6 +1062,7 @@ __global__ BBP_LANE_KERNEL void k_ipa_challenge(u32 B, u32 prev_round, u32 m, co
     sc* ms = misc + (size_t)p * MS_COUNT;
     st_sc(&ms[MS_UJ], u);
     st_sc(&ms[MS_UJI], sc_invert(u));
+    t.wave = 0;  // (memory never holds the flag: every kernel sets it for itself)
     tr[p] = t;
 }
 
@@ -1432,11 +1450,13 @@ __global__ __launch_bounds__(TAIL_BLK) void k_tail_lr(u32 B, u32 n, u32 prev_rou
 }
 
 __global__ BBP_LANE_KERNEL void k_ipa_final(u32 B, u32 m, const u32* __restrict__ enc, merlin_transcript* __restrict__ tr, sc* __restrict__ misc,
-                            const sc* __restrict__ a_all, const sc* __restrict__ b_all) {
+                            const sc* __restrict__ a_all, const sc* __restrict__ b_all, u32 wave) {
     BBP_THIN_PRIO();
     u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (wave) p >>= 6;  // one transcript per wavefront, every lane in lockstep (keccak_wave.h keccak_f1600_wave)
     if (p >= B) return;
     merlin_transcript t = tr[p];
+    t.wave = wave;
     const u32* e = enc + (size_t)p * enc_stride_words(m) + 8 * (m + 8) + 16 * 10;
     tr_append_words(t, LBL("L"), e);
     tr_append_words(t, LBL("R"), e + 8);
@@ -1446,6 +1466,7 @@ __global__ BBP_LANE_KERNEL void k_ipa_final(u32 B, u32 m, const u32* __restrict_
     sc* ms = misc + (size_t)p * MS_COUNT;
     st_sc(&ms[MS_A0], sc_add(sc_mul(ld_sc(&a[0]), u), sc_mul(ui, ld_sc(&a[1]))));
     st_sc(&ms[MS_B0], sc_add(sc_mul(ld_sc(&b[0]), ui), sc_mul(u, ld_sc(&b[1]))));
+    t.wave = 0;  // (memory never holds the flag: every kernel sets it for itself)
     tr[p] = t;
 }
 
@@ -1739,8 +1760,12 @@ int32_t prove_batch_dev(bbp_ctx* ctx, u32 B, u32 N, const u8* in_dev, const u8* 
                        (u32*)ctx->raw[sidx].p, bd.tr, bd.rng, c.n_cst, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v, bd.ai1, bd.ao1, 0u);
         } else {
             // prefix: one lane per proof, ~20 permutations (V x m, "m", the rng's rekeys, the first draw): 0.3 ms, no witness blocks
-            LAUNCH(ctx, TAG_RNG, k_open_serial, cdiv(B, 64), 64, s, B, cdiv(B, 64), m, n1, prefix, bd.enc, ent_dev, bd.vb, (u32*)ctx->raw[sidx].p,
-                   bd.tr, bd.rng, c.n_cst, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v, bd.ai1, bd.ao1, 1u);
+            if (B <= (u32)ctx->tr_wave_below)
+                LAUNCH(ctx, TAG_RNG, k_open_serial, B, 64, s, B, B, m, n1, prefix, bd.enc, ent_dev, bd.vb, (u32*)ctx->raw[sidx].p,
+                       bd.tr, bd.rng, c.n_cst, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v, bd.ai1, bd.ao1, 2u);
+            else
+                LAUNCH(ctx, TAG_RNG, k_open_serial, cdiv(B, 64), 64, s, B, cdiv(B, 64), m, n1, prefix, bd.enc, ent_dev, bd.vb, (u32*)ctx->raw[sidx].p,
+                       bd.tr, bd.rng, c.n_cst, c.w_terms, c.w_loff, c.w_roff, bd.cst, bd.v, bd.ai1, bd.ao1, 1u);
             // bulk: 32 lanes per proof for the draw chain + one lane per proof for the witness, in one launch of `cblk`-thread
             // workgroups that keep their CU to themselves (LDS hog): cblk / 32 proofs per rng workgroup
             // workgroup size: one wavefront (two proofs) per reserved CU is the fastest chain, but at 256 proofs that reserves 128 CUs
@@ -1851,7 +1876,8 @@ static int32_t prove_heavy(bbp_ctx* ctx, const CircuitDev& c, const BatchDev& bd
     // the three commitments of a proof in ONE launch (they sit B points apart: tmp[k * B + p]); three launches were three
     // dependent-chain latencies (3 x 82 us for a small call)
     LAUNCH(ctx, TAG_ENCODE, k_encode_strided, cdiv(3 * B, 64), 64, s, 3 * B, 3u, tmp, 1u, bd.enc, encw, 8 * m, B);
-    LAUNCH(ctx, TAG_TRANSCRIPT, k_tr_yz, cdiv(B, 64), 64, s, B, m, bd.enc, bd.tr, bd.misc);
+    const u32 tw = B <= (u32)ctx->tr_wave_below ? 1u : 0u, tgrid = tw ? B : cdiv(B, 64);  // transcript kernels: one proof per wavefront for small launches
+    LAUNCH(ctx, TAG_TRANSCRIPT, k_tr_yz, tgrid, 64, s, B, m, bd.enc, bd.tr, bd.misc, tw);
     {
         const u32 widest = c.n_cons + 1 > 2049u ? c.n_cons + 1 : 2049u;
         const PowersJob jz{c.n_cons + 1, (int)MS_Z, bd.zpow, c.n_cons + 1, 0u}, jy{2049u, (int)MS_Y, bd.ypow, 2049u, 0u}, jyi{2048u, (int)MS_YINV, bd.yipow, 2048u, 0u};
@@ -1862,19 +1888,19 @@ static int32_t prove_heavy(bbp_ctx* ctx, const CircuitDev& c, const BatchDev& bd
            bd.wo, bd.wv, 2048u);
     LAUNCH(ctx, TAG_POLY, k_poly, B, POLY_BLK, s, n1, bd.ai1, bd.ao1, bd.s1, bd.wl, bd.wr, bd.wo, 2048u, bd.ypow, bd.yipow, bd.l1, bd.r0,
            bd.r1, bd.r3, bd.misc);
-    LAUNCH(ctx, TAG_TRANSCRIPT, k_tr_tblind, cdiv(B, 64), 64, s, B, bd.rng, bd.misc);
+    LAUNCH(ctx, TAG_TRANSCRIPT, k_tr_tblind, tgrid, 64, s, B, bd.rng, bd.misc, tw);
     if (B * 5 <= (u32)ctx->commit_split_below)
         LAUNCH(ctx, TAG_COMMIT, k_commit_T_split, cdiv(B * 5 * COMMIT_L, 64), 64, s, B, bd.misc, ctx->comb, bd.pts, m + 8, m);
     else
         LAUNCH(ctx, TAG_COMMIT, k_commit_T, cdiv(B * 5, 64), 64, s, B, bd.misc, ctx->comb, bd.pts, m + 8, m);
     LAUNCH(ctx, TAG_ENCODE, k_encode_strided, cdiv(B * 5, 64), 64, s, B * 5, 5u, bd.pts + (m + 3), m + 8, bd.enc, encw, 8 * (m + 3), 1u);
-    LAUNCH(ctx, TAG_TRANSCRIPT, k_tr_ux, cdiv(B, 64), 64, s, B, m, n1, bd.enc, bd.wv, bd.vb, bd.ai1, bd.ao1, bd.s1, bd.tr, bd.misc);
+    LAUNCH(ctx, TAG_TRANSCRIPT, k_tr_ux, tgrid, 64, s, B, m, n1, bd.enc, bd.wv, bd.vb, bd.ai1, bd.ao1, bd.s1, bd.tr, bd.misc, tw);
     LAUNCH(ctx, TAG_POLY, k_lrvec, cdiv(B * 2048, 128), 128, s, B, n1, bd.l1, bd.r0, bd.r1, bd.r3, bd.ao1, bd.s1, bd.ypow, bd.yipow, bd.misc,
            bd.a, bd.b, bd.g, bd.h);
     // FOLD_ROUND (7), or 12 = never leave the fixed-base formulation (small heavy stages: context.h tail_small_below)
     const u32 tail_from = B < (u32)(ctx->tail_small_below > 0 ? ctx->tail_small_below : 0) ? 12u : (u32)ctx->tail_round;
     for (u32 r = 1; r <= 11 && r < tail_from; r++) {
-        if (r > 1) LAUNCH(ctx, TAG_TRANSCRIPT, k_ipa_challenge, cdiv(B, 64), 64, s, B, r - 1, m, bd.enc, bd.tr, bd.misc);
+        if (r > 1) LAUNCH(ctx, TAG_TRANSCRIPT, k_ipa_challenge, tgrid, 64, s, B, r - 1, m, bd.enc, bd.tr, bd.misc, tw);
         if (B <= (u32)ctx->ipa_wide_below)
             LAUNCH(ctx, TAG_IPA_SCALARS, k_ipa_round<IPA_BLK_WIDE>, B, IPA_BLK_WIDE, s, r, n1, bd.misc, bd.a, bd.b, bd.g, bd.h, bd.lr);
         else
@@ -1888,7 +1914,7 @@ static int32_t prove_heavy(bbp_ctx* ctx, const CircuitDev& c, const BatchDev& bd
         DevBuf& vt = ctx->slice_vtab[slot];
         if ((rc = dev_reserve(ctx, vt, (size_t)B * 2 * FOLD_CLS * TAIL_TAB * sizeof(ge)))) return rc;
         ge* ftab = static_cast<ge*>(vt.p);
-        LAUNCH(ctx, TAG_TRANSCRIPT, k_ipa_challenge, cdiv(B, 64), 64, s, B, tail_from - 1, m, bd.enc, bd.tr, bd.misc);
+        LAUNCH(ctx, TAG_TRANSCRIPT, k_ipa_challenge, tgrid, 64, s, B, tail_from - 1, m, bd.enc, bd.tr, bd.misc, tw);
         LAUNCH(ctx, TAG_IPA_SCALARS, k_ipa_round<IPA_BLK>, B, IPA_BLK, s, tail_from, n1, bd.misc, bd.a, bd.b, bd.g, bd.h, (sc*)nullptr);
         if ((rc = fold_generators_launch(ctx, B, bd.g, bd.h, bd.fpts, s, slot))) return rc;
         LAUNCH(ctx, TAG_VARBASE, k_tail_init, cdiv(B * FOLD_CLS, 64), 64, s, B, bd.g, bd.h);
@@ -1900,7 +1926,7 @@ static int32_t prove_heavy(bbp_ctx* ctx, const CircuitDev& c, const BatchDev& bd
             LAUNCH(ctx, TAG_ENCODE, k_encode_strided, cdiv(2 * B, 64), 64, s, 2 * B, 2u, bd.lrpts, 2u, bd.enc, encw, 8 * (m + 8 + 2 * (r - 1)), 1u);
         }
     }
-    LAUNCH(ctx, TAG_TRANSCRIPT, k_ipa_final, cdiv(B, 64), 64, s, B, m, bd.enc, bd.tr, bd.misc, bd.a, bd.b);
+    LAUNCH(ctx, TAG_TRANSCRIPT, k_ipa_final, tgrid, 64, s, B, m, bd.enc, bd.tr, bd.misc, bd.a, bd.b, tw);
     // a slice on an internal stream runs ahead of the caller's: its records must not land in out_dev before the work that was
     // enqueued on the caller's stream ahead of this call (a consumer of the previous call's records, say) has finished
     if (out_guard) BBP_HIP_TRY(ctx, hipStreamWaitEvent(s, out_guard, 0));

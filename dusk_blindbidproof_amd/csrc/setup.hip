@@ -282,6 +282,7 @@ static int32_t init_body(int32_t device, bbp_ctx** out) {
     if (const char* e = getenv("BBP_WITNESS_NATIVE")) ctx->witness_native = atoi(e) != 0;
     if (const char* e = getenv("BBP_COMMIT_SPLIT_BELOW")) ctx->commit_split_below = atoi(e);
     if (const char* e = getenv("BBP_IPA_WIDE_BELOW")) ctx->ipa_wide_below = atoi(e);
+    if (const char* e = getenv("BBP_TR_WAVE_BELOW")) ctx->tr_wave_below = atoi(e);
     if (const char* e = getenv("BBP_RNG_BLOCK")) {
         const int v = atoi(e);
         ctx->rng_block = v >= 1024 ? 1024 : v >= 512 ? 512 : v >= 256 ? 256 : v >= 128 ? 128 : 64;

@@ -423,12 +423,15 @@ def test_engine_schedules_give_identical_bytes(bbp, oc, knobs):
         c2.close()
 
 
-@pytest.mark.parametrize("knob,value", [("BBP_MSM_SMALL", "1"), ("BBP_MSM_SMALL", "0"), ("BBP_COMMIT_SPLIT_BELOW", "0"), ("BBP_WITNESS_NATIVE", "0"), ("BBP_IPA_WIDE_BELOW", "0")])
+@pytest.mark.parametrize("knob,value", [("BBP_MSM_SMALL", "1"), ("BBP_MSM_SMALL", "0"), ("BBP_COMMIT_SPLIT_BELOW", "0"), ("BBP_WITNESS_NATIVE", "0"), ("BBP_IPA_WIDE_BELOW", "0"), ("BBP_TR_WAVE_BELOW", "0"),
+                                        ("BBP_TAIL_SMALL_BELOW", "0")])
 def test_small_call_paths_give_identical_bytes(bbp, oc, knob, value):
     """What only small launches take.  Launches of fewer than 128 MSMs are cut into sub-MSMs; those use 128 buckets and width-9
     digits (msm.hip msm_geom<2>) or, BBP_MSM_SMALL=0, the 1024 buckets of the unsplit kernels.  Pedersen-commitment launches of
     at most 1024 commitments put each on eight lanes (BBP_COMMIT_SPLIT_BELOW=0: one lane).  The cooperative opening launches write
-    the gates from the gadget wiring (BBP_WITNESS_NATIVE=0: interpreted).  Every way the records are the C oracle's, for one proof
+    the gates from the gadget wiring (BBP_WITNESS_NATIVE=0: interpreted); launches of at most 32 proofs run the transcript kernels
+    with one proof per wavefront (BBP_TR_WAVE_BELOW=0: one lane) -- also when the IPA tail kernels, which stay one-lane, follow them
+    (BBP_TAIL_SMALL_BELOW=0).  Every way the records are the C oracle's, for one proof
     (sixteen sub-MSMs per MSM) and for batches that are cut in fewer pieces."""
     import os
     old = os.environ.get(knob)
