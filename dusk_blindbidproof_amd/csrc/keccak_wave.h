@@ -45,7 +45,6 @@ BBP_HD u64 kw_spread(u32 v) {
 BBP_HD u32 kw_half(u64 x, u32 h) { return kw_even_bits(h ? x >> 1 : x); }
 BBP_HD u64 kw_join(u32 even, u32 odd) { return kw_spread(even) | (kw_spread(odd) << 1); }
 
-#if defined(__HIPCC__)
 struct kw_lane {
     int s0, s1, s2;    // ds_bpermute byte addresses of the (pre-rotated) sources of B[x][y], B[x+1][y], B[x+2][y], this lane's half
     u32 sh_rho;        // v_alignbit shift of this half's share of the rho rotation (applied at the source)
@@ -55,9 +54,9 @@ struct kw_lane {
     bool lower;        // lane < 32
 };
 
-__device__ __forceinline__ u32 kw_lane_of(u32 x, u32 y, u32 h) { return 32 * h + 16 * (y / 3) + 5 * (y % 3) + x; }
+BBP_HD u32 kw_lane_of(u32 x, u32 y, u32 h) { return 32 * h + 16 * (y / 3) + 5 * (y % 3) + x; }
 
-__device__ __forceinline__ kw_lane kw_setup(u32 L) {
+BBP_HD kw_lane kw_setup(u32 L) {
     const u32 h = L >> 5, pos = L & 15u, rr = (L >> 4) & 1u, x = pos % 5, y = 3 * rr + pos / 5;
     const bool live = pos < 15 && y < 5;
     const u32 RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
@@ -77,7 +76,9 @@ __device__ __forceinline__ kw_lane kw_setup(u32 L) {
     c.sh_rho = (32u - amt) & 31u;
     c.sh_theta = h ? 31u : 0u;
     c.live = live ? ~0u : 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" : "+v"(c.live));
+#endif
     c.word = (x + 5 * y) % 25;
     c.half = h;
     c.lower = L < 32;
@@ -90,7 +91,7 @@ __device__ __forceinline__ kw_lane kw_setup(u32 L) {
 struct kw_iota {
     u32 v[25], cp[25];  // [r]: the constant PENDING at the start of round r (none at r = 0); v[24]: the last round's, applied at the end
 };
-__device__ __forceinline__ kw_iota kw_iota_setup(u32 L) {
+BBP_HD kw_iota kw_iota_setup(u32 L) {
     const u64 RC[24] = {0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808Aull, 0x8000000080008000ull,
                         0x000000000000808Bull, 0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull,
                         0x000000000000008Aull, 0x0000000000000088ull, 0x0000000080008009ull, 0x000000008000000Aull,
@@ -110,6 +111,7 @@ __device__ __forceinline__ kw_iota kw_iota_setup(u32 L) {
     return k;
 }
 
+#if defined(__HIPCC__)
 #define BBP_KW_ROW_SHL(n) (0x100 + (n))
 #define BBP_KW_ROW_SHR(n) (0x110 + (n))
 

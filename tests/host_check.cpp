@@ -3,6 +3,7 @@
 #include <string.h>
 
 #include "../dusk_blindbidproof_amd/csrc/keccak.h"
+#include "../dusk_blindbidproof_amd/csrc/keccak_wave.h"
 #include "../dusk_blindbidproof_amd/csrc/point.h"
 #include "../dusk_blindbidproof_amd/csrc/scalar.h"
 
@@ -144,6 +145,101 @@ int hc_scalarmult(const uint8_t* s32, const uint8_t* p32, uint8_t* out32) {
     }
     ge_encode(out32, acc);
     return 1;
+}
+
+// The bit-interleaved form the one-wavefront Keccak keeps its words in (keccak_wave.h): even / odd bits of x as two 32-bit halves.
+// 1 when the halves join back to x AND rotl64(x, r) is what the halves give under the rule kw_setup derives its lane shifts from
+// (even r: both halves rotate by r / 2; odd r: the halves change places, odd -> even by (r + 1) / 2, even -> odd by (r - 1) / 2).
+int hc_kw_interleave(uint64_t x, int r) {
+    const u32 e = kw_half(x, 0), o = kw_half(x, 1);
+    if (kw_join(e, o) != x) return 0;
+    auto rotl32 = [](u32 v, int k) { k &= 31; return k ? (u32)((v << k) | (v >> (32 - k))) : v; };
+    u32 e2, o2;
+    if (r % 2 == 0) {
+        e2 = rotl32(e, r / 2);
+        o2 = rotl32(o, r / 2);
+    } else {
+        e2 = rotl32(o, (r + 1) / 2);
+        o2 = rotl32(e, (r - 1) / 2);
+    }
+    const uint64_t want = r ? (x << r) | (x >> (64 - r)) : x;
+    return kw_join(e2, o2) == want ? 1 : 0;
+}
+
+// Host MODEL of the one-wavefront Keccak (keccak_wave.h BBP_KW_ROUND, instruction for instruction on arrays of 64 lanes): the lane
+// tables of kw_setup / kw_iota_setup are the product's own, the cross-lane operations are restated from the ISA (DPP row shifts with
+// bound_ctrl / bank masks, v_permlane16_swap, v_permlane32_swap, ds_bpermute).  What the CPU tier can say about the kernel: the
+// layout, the shift amounts, the gather addresses and the order of operations permute like Keccak-f[1600].
+struct KwVec {
+    u32 v[64];
+};
+static KwVec kw_dpp_shl(const KwVec& a, int n) {  // row_shl:n bound_ctrl: lane i reads lane i + n of its 16-lane row, 0 past the row
+    KwVec r;
+    for (int L = 0; L < 64; L++) r.v[L] = (L & 15) + n < 16 ? a.v[L + n] : 0u;
+    return r;
+}
+static KwVec kw_dpp_shr(const KwVec& a, int n) {
+    KwVec r;
+    for (int L = 0; L < 64; L++) r.v[L] = (L & 15) - n >= 0 ? a.v[L - n] : 0u;
+    return r;
+}
+static u32 kw_rotr32(u32 x, u32 s) { s &= 31; return s ? (x >> s) | (x << (32 - s)) : x; }  // v_alignbit_b32 x, x, s
+void hc_kw_keccak_f(uint8_t* st200) {
+    u64 st[25];
+    memcpy(st, st200, 200);
+    kw_lane c[64];
+    kw_iota k[64];
+    KwVec x;
+    for (u32 L = 0; L < 64; L++) {
+        c[L] = kw_setup(L);
+        k[L] = kw_iota_setup(L);
+        x.v[L] = c[L].live ? kw_half(st[c[L].word], c[L].half) : 0u;
+    }
+    for (int r = 0; r < 24; r++) {
+        KwVec t0, t1, t2, t3, t4;
+        for (int L = 0; L < 64; L++) t0.v[L] = x.v[L] ^ k[L].v[r];                      // a = x ^ pending iota
+        const KwVec s5 = kw_dpp_shl(x, 5), s10 = kw_dpp_shl(x, 10), r5 = kw_dpp_shr(x, 5), r10 = kw_dpp_shr(x, 10);
+        for (int L = 0; L < 64; L++) {
+            t1.v[L] = x.v[L] ^ s5.v[L] ^ r10.v[L];
+            t2.v[L] = s10.v[L];
+            t3.v[L] = r5.v[L];
+            t4.v[L] = t1.v[L] ^ t2.v[L] ^ t3.v[L];
+            t1.v[L] = t4.v[L];
+        }
+        // v_permlane16_swap t1, t4: rows (a0, a1, a2, a3), (b0, b1, b2, b3) -> (a0, b0, a2, b2), (a1, b1, a3, b3)
+        KwVec A = t1, Bv = t4;
+        for (int L = 0; L < 16; L++) {
+            t1.v[16 + L] = Bv.v[L];       t4.v[L] = A.v[16 + L];
+            t1.v[48 + L] = Bv.v[32 + L];  t4.v[32 + L] = A.v[48 + L];
+        }
+        for (int L = 0; L < 64; L++) {
+            t2.v[L] = t1.v[L] ^ t4.v[L] ^ k[L].cp[r];                                  // C of this lane's half
+            t3.v[L] = kw_rotr32(t2.v[L], c[L].sh_theta);
+        }
+        KwVec um = kw_dpp_shr(t2, 1), nx = kw_dpp_shl(t3, 1);
+        for (int L = 0; L < 64; L++) {
+            const int pos = L & 15;
+            if (pos < 4) um.v[L] = t2.v[L + 4];   // row_shl:4 bank_mask:0x1 (source always inside the row)
+            if (pos >= 8) nx.v[L] = t3.v[L - 4];  // row_shr:4 bank_mask:0xc
+        }
+        // v_permlane32_swap t4 (= nx), t2 (= copy): (lo, hi), (lo', hi') -> (lo, lo'), (hi, hi')
+        KwVec P = nx, Q = nx;
+        for (int L = 0; L < 32; L++) {
+            P.v[32 + L] = nx.v[L];  // vdst upper half <- src lower half
+            Q.v[L] = nx.v[32 + L];  // src lower half <- vdst upper half
+        }
+        for (int L = 0; L < 64; L++) {
+            const u32 d = um.v[L] ^ nx.v[L] ^ P.v[L] ^ Q.v[L];
+            t0.v[L] = kw_rotr32(t0.v[L] ^ (d & c[L].live), c[L].sh_rho);
+        }
+        for (int L = 0; L < 64; L++) {
+            const u32 b0 = t0.v[c[L].s0 / 4], b1 = t0.v[c[L].s1 / 4], b2 = t0.v[c[L].s2 / 4];
+            x.v[L] = b0 ^ (~b1 & b2);
+        }
+    }
+    for (u32 L = 0; L < 32; L++)
+        if (c[L].live) st[c[L].word] = kw_join(x.v[L] ^ k[L].v[24], x.v[L + 32] ^ k[L + 32].v[24]);
+    memcpy(st200, st, 200);
 }
 
 void hc_keccak_f(uint8_t* st200) {

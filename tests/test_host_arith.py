@@ -177,6 +177,33 @@ def test_rng_bulk_draws_equal_generic_path(lib):
         assert b"".join(r.fill_bytes(64) for _ in range(count + 2)) == a.raw
 
 
+def test_bit_interleaved_words_rotate_as_the_wave_keccak_assumes(lib):
+    """keccak_wave.h keeps every 64-bit state word as (even bits, odd bits): a 64-bit rotation must be a 32-bit rotation of each
+    half, with the halves changing places for odd amounts -- the rule the lane shifts and the rho-pi gather addresses are built from.
+    All 64 amounts on random and edge words."""
+    import ctypes, random
+    lib.hc_kw_interleave.argtypes = [ctypes.c_uint64, ctypes.c_int]
+    lib.hc_kw_interleave.restype = ctypes.c_int
+    rnd = random.Random(50)
+    words = [0, 1, 2, 1 << 63, (1 << 64) - 1, 0x5555555555555555, 0xAAAAAAAAAAAAAAAA, 0x0123456789ABCDEF] + [rnd.getrandbits(64) for _ in range(200)]
+    for x in words:
+        for r in range(64):
+            assert lib.hc_kw_interleave(x, r) == 1, (hex(x), r)
+
+
+def test_wave_keccak_model_permutes_like_keccak_f(lib):
+    """tests/host_check.cpp hc_kw_keccak_f: the one-wavefront Keccak of keccak_wave.h restated on arrays of 64 lanes with the
+    PRODUCT's lane tables (layout, theta / rho shift amounts, gather addresses, per-round iota vectors).  It must be Keccak-f[1600]."""
+    import ctypes
+    for seed in (b"a", b"bb", b"ccc", b""):
+        st = bytearray(hashlib.shake_256(b"kw" + seed).digest(200)) if seed else bytearray(200)
+        want = bytearray(st)
+        merlin.keccak_f1600(want)
+        buf = ctypes.create_string_buffer(bytes(st), 200)
+        lib.hc_kw_keccak_f(buf)
+        assert buf.raw == bytes(want)
+
+
 def test_keccak_and_merlin(lib):
     st = bytearray(hashlib.shake_256(b"st").digest(200))
     st2 = bytearray(st)
