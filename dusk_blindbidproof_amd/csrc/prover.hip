@@ -30,6 +30,7 @@
 #include "batch.h"
 #include "hosthash.h"
 #include "keccak_wave.h"
+#include "witness.h"
 
 namespace bbp {
 
@@ -124,90 +125,21 @@ __global__ void k_witness_head(u32 B, u32 n_items, u32 n_cst, const u8* __restri
     for (u32 i = 0; i < n_items; i++) st_sc(&v[4 + i], (u64)i == toggle ? sc_one() : sc_zero());
 }
 
-// gates: one lane interprets the compiled gadget program of its proof (sequential MiMC chains) -> a_L, a_R, a_O
+// gates: one lane per proof, interpreting the compiled gadget program or writing the gadget wiring out (witness.h: both forms, host + device)
 __device__ void witness_gates_lane(u32 p, u32 m, u32 n_mul, u32 n_cst, const u32* w_terms, const u32* w_loff,
                                    const u32* w_roff, const sc* __restrict__ cst_all, const sc* __restrict__ v_all,
                                    sc* __restrict__ ai1_all, sc* __restrict__ ao1_all) {
-    const sc* cst = cst_all + (size_t)p * n_cst;
-    const sc* v = v_all + (size_t)p * m;
     sc* aL = ai1_all + (size_t)p * (1 + 2 * n_mul) + 1;
-    sc* aR = aL + n_mul;
-    sc* aO = ao1_all + (size_t)p * (1 + n_mul) + 1;
-    for (u32 i = 0; i < n_mul; i++) {
-        sc lr[2];
-        const u32 bounds[3] = {w_loff[i], w_roff[i], w_loff[i + 1]};
-        for (int side = 0; side < 2; side++) {
-            sc acc = sc_zero();
-            for (u32 t = bounds[side]; t < bounds[side + 1]; t++) {
-                const u32 w = w_terms[t], kind = w >> 29, idx = w & 0x0fffffffu;
-                const sc* src = kind == 4 ? &cst[idx] : kind == 3 ? &aO[idx] : kind == 1 ? &aL[idx] : kind == 2 ? &aR[idx] : &v[idx];
-                sc val = ld_sc(src);
-                acc = ((w >> 28) & 1u) ? sc_sub(acc, val) : sc_add(acc, val);
-            }
-            lr[side] = acc;
-        }
-        st_sc(&aL[i], lr[0]);
-        st_sc(&aR[i], lr[1]);
-        st_sc(&aO[i], sc_mul(lr[0], lr[1]));
-    }
+    witness_gates_interpret(n_mul, w_terms, w_loff, w_roff, cst_all + (size_t)p * n_cst, v_all + (size_t)p * m, aL, aL + n_mul,
+                            ao1_all + (size_t)p * (1 + n_mul) + 1);
 }
-
-// The same gates WITHOUT the program: the gadget wiring of the reference written out (src/gadgets.rs:6-34 proof_gadget, :37-68
-// mimc_gadget, :88-132 one_of_many_gadget, :134-140 boolean_gadget, :70-86 score_gadget; the multiplier order is the call order,
-// as in circuit.h's generic synthesis).  Values stay in registers along a MiMC chain -- the interpreter fetches every operand it
-// stored one multiplier earlier back from memory, which is its whole running time (5.9 ms per proof against 1.1 here).  Both
-// forms must produce the same a_L, a_R, a_O (canonical scalars): every record test compares the proof bytes with the oracle under
-// each (BBP_WITNESS_NATIVE=0 keeps the interpreter; launches with one lane per proof for the draw chain always use it).
-__device__ sc witness_mimc_native(sc x, const sc& key, const sc* __restrict__ cst, sc* __restrict__ aL, sc* __restrict__ aR, sc* __restrict__ aO, u32 base) {
-    for (u32 i = 0; i < (u32)BBP_MIMC_ROUNDS; i++) {
-        const sc a = sc_add(sc_add(x, key), ld_sc(&cst[circuit::CST_MIMC0 + i]));
-        const sc a2 = sc_mul(a, a), a3 = sc_mul(a2, a), a4 = sc_mul(a2, a2), a7 = sc_mul(a4, a3);
-        const u32 j = base + 4 * i;
-        st_sc(&aL[j], a);      st_sc(&aR[j], a);      st_sc(&aO[j], a2);
-        st_sc(&aL[j + 1], a2); st_sc(&aR[j + 1], a);  st_sc(&aO[j + 1], a3);
-        st_sc(&aL[j + 2], a2); st_sc(&aR[j + 2], a2); st_sc(&aO[j + 2], a4);
-        st_sc(&aL[j + 3], a4); st_sc(&aR[j + 3], a3); st_sc(&aO[j + 3], a7);
-        x = a7;
-    }
-    return sc_add(x, key);
-}
+// The interpreter fetches every operand it stored one multiplier earlier back from memory, which is its whole running time (5.9 ms
+// per proof against 1.1 for the written-out wiring); BBP_WITNESS_NATIVE=0 keeps it, and the launches with one lane per proof
+// for the draw chain always use it.
 __device__ void witness_gates_native_lane(u32 p, u32 m, u32 n_mul, u32 n_cst, const sc* __restrict__ cst_all, const sc* __restrict__ v_all,
                                           sc* __restrict__ ai1_all, sc* __restrict__ ao1_all) {
-    const sc* cst = cst_all + (size_t)p * n_cst;
-    const sc* v = v_all + (size_t)p * m;
     sc* aL = ai1_all + (size_t)p * (1 + 2 * n_mul) + 1;
-    sc* aR = aL + n_mul;
-    sc* aO = ao1_all + (size_t)p * (1 + n_mul) + 1;
-    const u32 N = m - 4, R4 = 4 * (u32)BBP_MIMC_ROUNDS;
-    const sc d = ld_sc(&v[0]), k = ld_sc(&v[1]), y_inv = ld_sc(&v[3]), seed = ld_sc(&cst[circuit::CST_SEED]);
-    const sc mm = witness_mimc_native(k, sc_zero(), cst, aL, aR, aO, 0);      // m = H(k)
-    const sc x = witness_mimc_native(d, mm, cst, aL, aR, aO, R4);             // x = H(d, m)
-    u32 j = 2 * R4;
-    for (u32 i = 0; i < N; i++, j++) {                                       // toggle bits are bits: t (1 - t) = 0
-        const sc t = ld_sc(&v[4 + i]), nt = sc_sub(sc_one(), t);
-        st_sc(&aL[j], t);
-        st_sc(&aR[j], nt);
-        st_sc(&aO[j], sc_mul(t, nt));
-    }
-    for (u32 i = 0; i < N; i++, j += 2) {                                    // item_i t_i = t_i x
-        const sc t = ld_sc(&v[4 + i]), item = ld_sc(&cst[circuit::CST_ITEM0 + i]);
-        st_sc(&aL[j], item);
-        st_sc(&aR[j], t);
-        st_sc(&aO[j], sc_mul(item, t));
-        st_sc(&aL[j + 1], t);
-        st_sc(&aR[j + 1], x);
-        st_sc(&aO[j + 1], sc_mul(t, x));
-    }
-    const sc y = witness_mimc_native(seed, x, cst, aL, aR, aO, j);            // y = H(seed, x)
-    witness_mimc_native(seed, mm, cst, aL, aR, aO, j + R4);                   // z = H(seed, m): constrained against z_img, not multiplied further
-    j += 2 * R4;
-    st_sc(&aL[j], y);                                                        // score: y y_inv = 1, d y_inv = q
-    st_sc(&aR[j], y_inv);
-    st_sc(&aO[j], sc_mul(y, y_inv));
-    st_sc(&aL[j + 1], d);
-    st_sc(&aR[j + 1], y_inv);
-    st_sc(&aO[j + 1], sc_mul(d, y_inv));
-    // (j + 2 == n_mul: circuit.h's synthesis and this function count the same multipliers; checked on the host at compile time of the circuit)
+    witness_gates_native(m - 4, cst_all + (size_t)p * n_cst, v_all + (size_t)p * m, aL, aL + n_mul, ao1_all + (size_t)p * (1 + n_mul) + 1);
 }
 
 // The witness blocks of the cooperative opening launches (one lane per proof).  The interpreter's time is its dependent loads --

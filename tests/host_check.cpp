@@ -2,10 +2,13 @@
 // tier can compare them with the oracle.  Nothing in the shipped library calls this.
 #include <string.h>
 
+#include <vector>
+
 #include "../dusk_blindbidproof_amd/csrc/keccak.h"
 #include "../dusk_blindbidproof_amd/csrc/keccak_wave.h"
 #include "../dusk_blindbidproof_amd/csrc/point.h"
 #include "../dusk_blindbidproof_amd/csrc/scalar.h"
+#include "../dusk_blindbidproof_amd/csrc/witness.h"
 
 using namespace bbp;
 
@@ -145,6 +148,53 @@ int hc_scalarmult(const uint8_t* s32, const uint8_t* p32, uint8_t* out32) {
     }
     ge_encode(out32, acc);
     return 1;
+}
+
+// The prover's gates a_L | a_R | a_O of one proof on the host, from the product's own code (csrc/witness.h): the compiled gadget
+// program interpreted (circuit.h compile + witness_gates_interpret) and the gadget wiring written out (witness_gates_native).
+// in_raw: d, k, y, y_inv, q, z_img, seed (7 x 32 B) || N items (32 B each) || toggle (u64), as Proof::prove's inputs reach the engine;
+// mimc: the 90 round constants (32 B each).  out_*: 3 * n_mul scalars each (a_L, then a_R, then a_O).  Returns n_mul, or -1 / -2 when
+// the two forms do not count the same multipliers / the buffers are too small.
+int hc_witness_gates(uint32_t n_items, const uint8_t* in_raw, const uint8_t* mimc, uint8_t* out_interp, uint8_t* out_native, uint32_t cap_mul) {
+    const circuit::Compiled c = circuit::compile(n_items);
+    if (c.n_mul > cap_mul) return -2;
+    std::vector<sc> cst(circuit::cst_count(n_items)), v(4 + n_items);
+    u32 w[8];
+    sc s7[7];
+    for (int i = 0; i < 7; i++) {
+        ld(w, in_raw + 32 * i, 8);
+        s7[i] = sc_reduce256(w);
+    }
+    cst[circuit::CST_ONE] = sc_one();
+    cst[circuit::CST_ZERO] = sc_zero();
+    for (int i = 0; i < circuit::MIMC_ROUNDS; i++) {
+        ld(w, mimc + 32 * i, 8);
+        cst[circuit::CST_MIMC0 + i] = sc_reduce256(w);
+    }
+    cst[circuit::CST_SEED] = s7[6];
+    cst[circuit::CST_ZIMG] = s7[5];
+    cst[circuit::CST_Q] = s7[4];
+    for (uint32_t i = 0; i < n_items; i++) {
+        ld(w, in_raw + 224 + 32 * i, 8);
+        cst[circuit::CST_ITEM0 + i] = sc_from_bits(w);  // bid.rs:27
+    }
+    uint64_t toggle;
+    memcpy(&toggle, in_raw + 224 + 32 * (size_t)n_items, 8);
+    v[0] = s7[0];
+    v[1] = s7[1];
+    v[2] = s7[2];
+    v[3] = s7[3];
+    for (uint32_t i = 0; i < n_items; i++) v[4 + i] = (uint64_t)i == toggle ? sc_one() : sc_zero();
+    std::vector<sc> a(3 * (size_t)c.n_mul), b(3 * (size_t)c.n_mul);
+    witness_gates_interpret(c.n_mul, c.w_terms.data(), c.w_loff.data(), c.w_roff.data(), cst.data(), v.data(), a.data(), a.data() + c.n_mul,
+                            a.data() + 2 * (size_t)c.n_mul);
+    const u32 wrote = witness_gates_native(n_items, cst.data(), v.data(), b.data(), b.data() + c.n_mul, b.data() + 2 * (size_t)c.n_mul);
+    if (wrote != c.n_mul) return -1;
+    for (size_t i = 0; i < a.size(); i++) {
+        memcpy(out_interp + 32 * i, a[i].v, 32);
+        memcpy(out_native + 32 * i, b[i].v, 32);
+    }
+    return (int)c.n_mul;
 }
 
 // The bit-interleaved form the one-wavefront Keccak keeps its words in (keccak_wave.h): even / odd bits of x as two 32-bit halves.

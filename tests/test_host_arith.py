@@ -177,6 +177,45 @@ def test_rng_bulk_draws_equal_generic_path(lib):
         assert b"".join(r.fill_bytes(64) for _ in range(count + 2)) == a.raw
 
 
+def test_gate_assignments_interpreted_native_and_oracle_agree(lib):
+    """csrc/witness.h on the host: a_L, a_R, a_O of one proof from (a) the compiled gadget program interpreted, (b) the gadget wiring
+    written out (what the cooperative opening launches run), (c) the big-int oracle's Prover driven through the same gadgets
+    (oracle/ref_py, src/gadgets.rs in call order).  All three must be the same canonical scalars, for several list lengths, toggle
+    positions (including one outside the list: no bit set) and an input above the group order."""
+    import ctypes, random
+    from oracle.ref_py import blindbid as bb, r1cs
+    L = r1cs.L
+
+    class ValuesOnly(r1cs.Prover):
+        def __init__(self, values):
+            r1cs._CSBase.__init__(self)
+            self.v, self.vb = [x % L for x in values], []
+            self.aL, self.aR, self.aO = [], [], []
+
+    rnd = random.Random(81)
+    mimc = bb.mimc_constants(bb.MIMC_ROUNDS)
+    mimc_raw = b"".join(int(c).to_bytes(32, "little") for c in mimc)
+    lib.hc_witness_gates.restype = ctypes.c_int
+    for n, toggle in ((1, 0), (2, 1), (8, 3), (8, 2 ** 32 + 3), (13, 12), (40, 0)):
+        seven = [rnd.randrange(L) for _ in range(7)]
+        seven[0] = L + 5  # d is reduced on the way in
+        items = [rnd.getrandbits(256) for _ in range(n)]
+        raw = b"".join(x.to_bytes(32, "little") for x in seven) + b"".join(x.to_bytes(32, "little") for x in items) + toggle.to_bytes(8, "little")
+        cap = 2048
+        a, b = ctypes.create_string_buffer(3 * cap * 32), ctypes.create_string_buffer(3 * cap * 32)
+        n_mul = lib.hc_witness_gates(n, raw, mimc_raw, a, b, cap)
+        assert n_mul == 4 * 4 * bb.MIMC_ROUNDS + 3 * n + 2
+        assert a.raw[:3 * n_mul * 32] == b.raw[:3 * n_mul * 32]
+        d, k, y, y_inv, q, z_img, seed = [x % L for x in seven]
+        cs = ValuesOnly([d, k, y, y_inv] + [1 if i == toggle else 0 for i in range(n)])
+        t_v = [(r1cs.COMMITTED, 4 + i) for i in range(n)]
+        bb.proof_gadget(cs, r1cs.LC.of((r1cs.COMMITTED, 0)), r1cs.LC.of((r1cs.COMMITTED, 1)), r1cs.LC.of((r1cs.COMMITTED, 3)), r1cs.LC.of(q),
+                        r1cs.LC.of(z_img), r1cs.LC.of(seed), mimc, t_v, [r1cs.LC.of((x & ((1 << 255) - 1)) % L) for x in items])  # Scalar::from_bits (bid.rs:27): bit 255 cleared
+        assert cs.n_mul == n_mul
+        want = b"".join(int(x).to_bytes(32, "little") for x in cs.aL + cs.aR + cs.aO)
+        assert a.raw[:3 * n_mul * 32] == want, n
+
+
 def test_bit_interleaved_words_rotate_as_the_wave_keccak_assumes(lib):
     """keccak_wave.h keeps every 64-bit state word as (even bits, odd bits): a 64-bit rotation must be a 32-bit rotation of each
     half, with the halves changing places for odd amounts -- the rule the lane shifts and the rho-pi gather addresses are built from.
