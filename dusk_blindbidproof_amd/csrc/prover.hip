@@ -785,6 +785,39 @@ __global__ void k_flatten(u32 B, u32 n_tgt, u32 n_mul, u32 m, const u32* __restr
                               : &wv[(size_t)p * m + (k - 3 * n_mul)];
     st_sc(dst, acc);
 }
+// k_flatten for launches of a few proofs: a target on FLAT_L lanes (lane q takes the entries e0 + q, e0 + q + FLAT_L, ...; three shuffle
+// steps add the partial sums).  A MiMC key or the hash input x sits in several hundred constraints: one lane per target is a 200 us
+// chain for ONE proof however its loads are batched.
+constexpr int FLAT_L = 8;
+__global__ void k_flatten_split(u32 B, u32 n_tgt, u32 n_mul, u32 m, const u32* __restrict__ f_off, const u32* __restrict__ f_ent,
+                                const sc* __restrict__ zpow, u32 zstride, sc* __restrict__ wl, sc* __restrict__ wr, sc* __restrict__ wo,
+                                sc* __restrict__ wv, u32 wstride) {
+    BBP_THIN_PRIO();
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x, g = t / FLAT_L, q = t % FLAT_L;
+    const u32 gi = g < B * n_tgt ? g : B * n_tgt - 1;  // whole wavefronts reach the shuffles
+    const u32 p = gi / n_tgt, k = gi % n_tgt;
+    const sc* zp = zpow + (size_t)p * zstride;
+    sc acc = sc_zero();
+    const u32 e1 = f_off[k + 1];
+    for (u32 e = f_off[k] + q; e < e1; e += FLAT_L) {
+        const u32 w = f_ent[e];
+        const sc zq = ld_sc(&zp[(w & 0x7fffffffu) + 1]);
+        acc = (w >> 31) ? sc_sub(acc, zq) : sc_add(acc, zq);
+    }
+#pragma unroll 1
+    for (int d = FLAT_L / 2; d >= 1; d >>= 1) {
+        sc o;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o.v[i] = (u32)__shfl_down((int)acc.v[i], d, 64);
+        acc = sc_add(acc, o);  // (lanes whose partner lies in the next group add something nobody reads)
+    }
+    if (q != 0 || g >= B * n_tgt) return;
+    sc* dst = k < n_mul ? &wl[(size_t)p * wstride + k]
+              : k < 2 * n_mul ? &wr[(size_t)p * wstride + (k - n_mul)]
+              : k < 3 * n_mul ? &wo[(size_t)p * wstride + (k - 2 * n_mul)]
+                              : &wv[(size_t)p * m + (k - 3 * n_mul)];
+    st_sc(dst, acc);
+}
 
 // block-wide sum of NV scalars per lane through LDS (BLK lanes); result valid in lane 0
 template <int NV, int BLK>
@@ -1816,7 +1849,11 @@ static int32_t prove_heavy(bbp_ctx* ctx, const CircuitDev& c, const BatchDev& bd
         LAUNCH(ctx, TAG_POLY, k_powers3, dim3(cdiv(B * cdiv(widest, 32), 64), 3), 64, s, B, bd.misc, jz, jy, jyi);
     }
     const u32 n_tgt = 3 * n1 + m;
-    LAUNCH(ctx, TAG_POLY, k_flatten, cdiv(B * n_tgt, 128), 128, s, B, n_tgt, n1, m, c.f_off, c.f_ent, bd.zpow, c.n_cons + 1, bd.wl, bd.wr,
+    if (B <= (u32)ctx->ipa_wide_below)
+        LAUNCH(ctx, TAG_POLY, k_flatten_split, cdiv(B * n_tgt * FLAT_L, 128), 128, s, B, n_tgt, n1, m, c.f_off, c.f_ent, bd.zpow, c.n_cons + 1, bd.wl, bd.wr,
+           bd.wo, bd.wv, 2048u);
+    else
+        LAUNCH(ctx, TAG_POLY, k_flatten, cdiv(B * n_tgt, 128), 128, s, B, n_tgt, n1, m, c.f_off, c.f_ent, bd.zpow, c.n_cons + 1, bd.wl, bd.wr,
            bd.wo, bd.wv, 2048u);
     LAUNCH(ctx, TAG_POLY, k_poly, B, POLY_BLK, s, n1, bd.ai1, bd.ao1, bd.s1, bd.wl, bd.wr, bd.wo, 2048u, bd.ypow, bd.yipow, bd.l1, bd.r0,
            bd.r1, bd.r3, bd.misc);
